@@ -1,0 +1,21 @@
+"""groth16_amd -- MI355X-native Groth16 prover hot path behind ark-groth16's prover API.
+
+Host-side mirror (Python, because no Rust toolchain exists in this image) of the reference's
+prover interface for the accelerated path; everything below the method signatures goes through
+the C ABI of ``libg16_mi355x.so`` (include/g16_mi355x.h) -- there is no CPU fallback.
+
+Reference interface mirrored (paths relative to /root/reference):
+  Groth16.create_proof_with_reduction_and_matrices   src/prover.rs:26-51
+  Groth16.create_proof_with_reduction_no_zk          src/prover.rs:155-168 (matrices form)
+  Groth16.create_random_proof_with_reduction         src/prover.rs:138-150 (matrices form)
+  LibsnarkReduction.witness_map_from_matrices        src/r1cs_to_qap.rs:172-235
+  ProvingKey / Proof / ConstraintMatrices            src/data_structures.rs:8-16,125-143
+  SynthesisError.PolynomialDegreeTooLarge            src/r1cs_to_qap.rs:178-179
+"""
+from .binding import (G16Error, Lib, PolynomialDegreeTooLarge, SynthesisError, lib, FQ_LIMBS, CURVE_ID)  # noqa: F401
+from .groth16 import ConstraintMatrices, Groth16, LibsnarkReduction, Proof, ProvingKey, ShardedProver  # noqa: F401
+
+__all__ = [
+    "Groth16", "LibsnarkReduction", "ConstraintMatrices", "ProvingKey", "Proof", "ShardedProver", "G16Error", "SynthesisError",
+    "PolynomialDegreeTooLarge", "lib",
+]

@@ -1,0 +1,151 @@
+"""ctypes binding of include/g16_mi355x.h.  Loading fails loudly: the product has no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libg16_mi355x.so")
+
+CURVE_ID = {"bls12_381": 0, "bn254": 1}
+FQ_LIMBS = {"bls12_381": 6, "bn254": 4}
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+
+
+class G16Error(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"g16 status {status}: {msg}")
+        self.status = status
+
+
+class SynthesisError(G16Error):
+    """mirrors ark_relations::r1cs::SynthesisError for the variants this path can produce"""
+
+
+class PolynomialDegreeTooLarge(SynthesisError):
+    pass
+
+
+class QueryC(C.Structure):
+    _fields_ = [("points", C.c_void_p), ("count", C.c_uint64), ("start", C.c_uint64)]
+
+
+class PkViewC(C.Structure):
+    _fields_ = [
+        ("alpha_g1", u64p), ("beta_g1", u64p), ("delta_g1", u64p), ("beta_g2", u64p), ("delta_g2", u64p),
+        ("a_query0", u64p), ("b_g1_query0", u64p), ("b_g2_query0", u64p),
+        ("a", QueryC), ("b_g1", QueryC), ("b_g2", QueryC), ("h", QueryC), ("l", QueryC),
+        ("flags", C.c_uint32),
+    ]
+
+
+class CsrViewC(C.Structure):
+    _fields_ = [("row_ptr", u64p), ("col", u32p), ("val", u64p)]
+
+
+class ProofC(C.Structure):
+    _fields_ = [("a", C.c_uint64 * 12), ("b", C.c_uint64 * 24), ("c", C.c_uint64 * 12)]
+
+
+class PartialC(C.Structure):
+    _fields_ = [("h", C.c_uint64 * 24), ("l", C.c_uint64 * 24), ("a", C.c_uint64 * 24), ("b_g1", C.c_uint64 * 24),
+                ("b_g2", C.c_uint64 * 48)]
+
+
+class TimingsC(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_a_ms", "msm_b_g1_ms", "msm_b_g2_ms", "scalar_prep_ms", "finish_ms",
+        "total_ms", "bucket_pass_ms")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = [
+    "g16_ctx_create", "g16_ctx_destroy", "g16_ctx_stream", "g16_pk_load", "g16_pk_free", "g16_circuit_load", "g16_circuit_free",
+    "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_get_timings", "g16_witness_map",
+    "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
+    "g16_host_msm_model", "g16_strerror", "g16_last_error", "g16_version",
+]
+
+
+def ptr64(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "expected a C-contiguous uint64 array"
+    return a.ctypes.data_as(u64p)
+
+
+def ptr32(a: np.ndarray):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+class Lib:
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  groth16_amd has no CPU fallback.")
+        self.path = path
+        self.c = C.CDLL(path)
+        c = self.c
+        c.g16_strerror.restype = C.c_char_p
+        c.g16_last_error.restype = C.c_char_p
+        c.g16_version.restype = C.c_char_p
+        c.g16_ctx_stream.restype = C.c_void_p
+        c.g16_ctx_stream.argtypes = [C.c_void_p]
+        c.g16_circuit_domain_size.restype = C.c_uint64
+        c.g16_circuit_domain_size.argtypes = [C.c_void_p]
+        c.g16_ctx_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        c.g16_ctx_destroy.argtypes = [C.c_void_p]
+        c.g16_ctx_destroy.restype = None
+        c.g16_pk_load.argtypes = [C.c_void_p, C.POINTER(PkViewC), C.POINTER(C.c_void_p)]
+        c.g16_pk_free.argtypes = [C.c_void_p]
+        c.g16_pk_free.restype = None
+        c.g16_circuit_load.argtypes = [C.c_void_p, C.POINTER(CsrViewC), C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+        c.g16_circuit_free.argtypes = [C.c_void_p]
+        c.g16_circuit_free.restype = None
+        c.g16_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, u64p, u64p, C.POINTER(ProofC)]
+        c.g16_prove_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
+                                        C.POINTER(PartialC)]
+        c.g16_prove_finalize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PartialC), C.c_int, u64p, u64p, C.POINTER(ProofC)]
+        c.g16_get_timings.argtypes = [C.c_void_p, C.POINTER(TimingsC)]
+        c.g16_witness_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, u64p]
+        c.g16_msm_g1.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, u64p]
+        c.g16_msm_g2.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, u64p]
+        c.g16_ntt.argtypes = [C.c_void_p, u64p, C.c_int, C.c_int, C.c_int]
+        c.g16_synth_bases.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+        c.g16_synth_circuit.argtypes = [C.c_int, C.c_int, C.c_uint64, u64p, u64p, u32p, u32p, u32p, u64p]
+        c.g16_host_field_op.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
+        c.g16_host_group_op.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
+        c.g16_host_msm_model.argtypes = [C.c_int, C.c_int, u64p, u64p, C.c_uint64, C.c_int, u64p]
+
+    def check(self, status: int):
+        if status == 0:
+            return
+        msg = self.c.g16_strerror(status).decode()
+        detail = self.c.g16_last_error().decode()
+        if detail:
+            msg += " | " + detail
+        if status == 1:
+            raise PolynomialDegreeTooLarge(status, msg)
+        raise G16Error(status, msg)
+
+    def version(self) -> str:
+        return self.c.g16_version().decode()
+
+
+_LIB: Optional[Lib] = None
+
+
+def lib() -> Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib()
+    return _LIB

@@ -1,0 +1,770 @@
+// C ABI of libg16_mi355x.so (declared in include/g16_mi355x.h): contexts, device-resident proving
+// keys and circuits, the prover orchestration and the unit-level entry points.
+//
+// Orchestration restates Groth16::create_proof_with_reduction_and_matrices
+// (/root/reference/src/prover.rs:26-51) and create_proof_with_assignment (:54-132): the witness
+// map and the five MSMs run on the GPU; the O(1) glue of :76-131 (six scalar multiples, a
+// handful of additions, three into_affine) runs on the host with the same field code.
+#include "internal.hpp"
+#include "msm_common.hpp"
+#include <chrono>
+#include <new>
+
+namespace g16 {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const char* what, hipError_t e, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+    g_last_error = buf;
+}
+
+int Arena::alloc(size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (auto& c : chunks) {
+        if (c.cap - c.used >= bytes) {
+            *out = c.p + c.used;
+            c.used += bytes;
+            return G16_OK;
+        }
+    }
+    Chunk c;
+    c.cap = bytes > min_chunk ? bytes : min_chunk;
+    c.used = 0;
+    c.p = nullptr;
+    G16_HIP_TRY(hipMalloc((void**)&c.p, c.cap));
+    c.used = bytes;
+    *out = c.p;
+    chunks.push_back(c);
+    return G16_OK;
+}
+void Arena::release() {
+    for (auto& c : chunks) (void)hipFree(c.p);
+    chunks.clear();
+}
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace g16
+
+using namespace g16;
+
+struct g16_ctx {
+    int curve;
+    int device;
+    hipStream_t stream;
+    Arena arena;
+    g16_timings tm;
+    EventTimer t_wm, t_prep_h, t_prep_z, t_msm[5], t_bucket[5];
+};
+
+struct g16_circuit {
+    int curve;
+    g16_ctx* ctx;
+    void* dc;  // DeviceCircuit<C>*
+    uint64_t domain_size;
+};
+
+template <class C>
+struct DevicePk {
+    typedef typename C::G1A G1A;
+    typedef typename C::G2A G2A;
+    G1A alpha_g1, beta_g1, delta_g1, a_query0, b_g1_query0;
+    G2A beta_g2, delta_g2, b_g2_query0;
+    G1A *a = nullptr, *b_g1 = nullptr, *h = nullptr, *l = nullptr;
+    G2A* b_g2 = nullptr;
+    uint64_t a_start = 0, a_count = 0, b_g1_start = 0, b_g1_count = 0, b_g2_start = 0, b_g2_count = 0;
+    uint64_t h_start = 0, h_count = 0, l_start = 0, l_count = 0;
+};
+
+struct g16_pk {
+    int curve;
+    g16_ctx* ctx;
+    void* dp;  // DevicePk<C>*
+};
+
+namespace {
+
+template <class T>
+T load_pod(const uint64_t* p) {
+    T t;
+    memcpy(&t, p, sizeof(T));
+    return t;
+}
+
+template <class C>
+struct Impl {
+    typedef typename C::Fr Fr;
+    typedef typename C::Fq Fq;
+    typedef typename C::Fq2 Fq2;
+    typedef typename C::G1A G1A;
+    typedef typename C::G2A G2A;
+    typedef typename C::G1X G1X;
+    typedef typename C::G2X G2X;
+    static constexpr int L = Fq::N / 2;  // 64-bit limbs per Fq
+
+    // ---------------------------------------------------------------------------------------
+    template <class P>
+    static int upload_query(g16_ctx* ctx, const g16_query& q, bool dev_ptrs, P** out) {
+        *out = nullptr;
+        if (q.count == 0) return G16_OK;
+        if (!q.points) return G16_ERR_BAD_ARG;
+        G16_HIP_TRY(hipMalloc((void**)out, q.count * sizeof(P)));
+        G16_HIP_TRY(hipMemcpyAsync(*out, q.points, q.count * sizeof(P), dev_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                   ctx->stream));
+        return G16_OK;
+    }
+
+    static void pk_free(DevicePk<C>* p) {
+        if (!p) return;
+        (void)hipFree(p->a); (void)hipFree(p->b_g1); (void)hipFree(p->b_g2); (void)hipFree(p->h); (void)hipFree(p->l);
+        delete p;
+    }
+
+    static int pk_load(g16_ctx* ctx, const g16_pk_view* v, g16_pk** out) {
+        if (!v->alpha_g1 || !v->beta_g1 || !v->delta_g1 || !v->beta_g2 || !v->delta_g2 || !v->a_query0 || !v->b_g1_query0 ||
+            !v->b_g2_query0)
+            return G16_ERR_BAD_ARG;
+        DevicePk<C>* p = new (std::nothrow) DevicePk<C>();
+        if (!p) return G16_ERR_OOM;
+        p->alpha_g1 = load_pod<G1A>(v->alpha_g1);
+        p->beta_g1 = load_pod<G1A>(v->beta_g1);
+        p->delta_g1 = load_pod<G1A>(v->delta_g1);
+        p->beta_g2 = load_pod<G2A>(v->beta_g2);
+        p->delta_g2 = load_pod<G2A>(v->delta_g2);
+        p->a_query0 = load_pod<G1A>(v->a_query0);
+        p->b_g1_query0 = load_pod<G1A>(v->b_g1_query0);
+        p->b_g2_query0 = load_pod<G2A>(v->b_g2_query0);
+        const bool dev = (v->flags & G16_PK_DEVICE_PTRS) != 0;
+        int rc = G16_OK;
+        if ((rc = upload_query<G1A>(ctx, v->a, dev, &p->a)) || (rc = upload_query<G1A>(ctx, v->b_g1, dev, &p->b_g1)) ||
+            (rc = upload_query<G2A>(ctx, v->b_g2, dev, &p->b_g2)) || (rc = upload_query<G1A>(ctx, v->h, dev, &p->h)) ||
+            (rc = upload_query<G1A>(ctx, v->l, dev, &p->l))) {
+            pk_free(p);
+            return rc;
+        }
+        p->a_start = v->a.start; p->a_count = v->a.count;
+        p->b_g1_start = v->b_g1.start; p->b_g1_count = v->b_g1.count;
+        p->b_g2_start = v->b_g2.start; p->b_g2_count = v->b_g2.count;
+        p->h_start = v->h.start; p->h_count = v->h.count;
+        p->l_start = v->l.start; p->l_count = v->l.count;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { pk_free(p); return G16_ERR_HIP; }
+        g16_pk* h = new (std::nothrow) g16_pk{C::CURVE_ID, ctx, p};
+        if (!h) { pk_free(p); return G16_ERR_OOM; }
+        *out = h;
+        return G16_OK;
+    }
+
+    // ---------------------------------------------------------------------------------------
+    static void circuit_free(DeviceCircuit<C>* dc) {
+        if (!dc) return;
+        for (int m = 0; m < 3; ++m) { (void)hipFree(dc->row_ptr[m]); (void)hipFree(dc->col[m]); (void)hipFree(dc->val[m]); }
+        domain_destroy<C>(dc->dom);
+        delete dc;
+    }
+
+    static int circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints, uint64_t num_variables,
+                            g16_circuit** out) {
+        if (num_inputs == 0 || num_variables < num_inputs) return G16_ERR_BAD_LENGTH;
+        // D::new(num_constraints + num_inputs), r1cs_to_qap.rs:178-179
+        const uint64_t need = num_constraints + num_inputs;
+        int log_n = 0;
+        while (((uint64_t)1 << log_n) < need) {
+            ++log_n;
+            if (log_n > 40) return G16_ERR_DEGREE_TOO_LARGE;
+        }
+        if (log_n > C::TWO_ADICITY) return G16_ERR_DEGREE_TOO_LARGE;
+        if (log_n > 30) return G16_ERR_DEGREE_TOO_LARGE;  // 32-bit indices inside the kernels
+        DeviceCircuit<C>* dc = new (std::nothrow) DeviceCircuit<C>();
+        if (!dc) return G16_ERR_OOM;
+        dc->num_inputs = num_inputs;
+        dc->num_constraints = num_constraints;
+        dc->num_variables = num_variables;
+        auto fail = [&](int code) { circuit_free(dc); return code; };
+        for (int m = 0; m < 3; ++m) {
+            if (!abc[m].row_ptr) return fail(G16_ERR_BAD_ARG);
+            const uint64_t nnz = abc[m].row_ptr[num_constraints];
+            dc->nnz[m] = nnz;
+            for (uint64_t k = 0; k < nnz; ++k)
+                if (abc[m].col[k] >= num_variables) return fail(G16_ERR_BAD_LENGTH);
+            if (hipMalloc((void**)&dc->row_ptr[m], (num_constraints + 1) * sizeof(uint64_t)) != hipSuccess) return fail(G16_ERR_OOM);
+            if (hipMalloc((void**)&dc->col[m], (nnz ? nnz : 1) * sizeof(uint32_t)) != hipSuccess) return fail(G16_ERR_OOM);
+            if (hipMalloc((void**)&dc->val[m], (nnz ? nnz : 1) * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
+            if (hipMemcpyAsync(dc->row_ptr[m], abc[m].row_ptr, (num_constraints + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) !=
+                hipSuccess)
+                return fail(G16_ERR_HIP);
+            if (nnz) {
+                if (hipMemcpyAsync(dc->col[m], abc[m].col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    return fail(G16_ERR_HIP);
+                if (hipMemcpyAsync(dc->val[m], abc[m].val, nnz * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    return fail(G16_ERR_HIP);
+            }
+        }
+        int rc = domain_create<C>(log_n, ctx->stream, &dc->dom);
+        if (rc) return fail(rc);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(G16_ERR_HIP);
+        g16_circuit* h = new (std::nothrow) g16_circuit{C::CURVE_ID, ctx, dc, (uint64_t)1 << log_n};
+        if (!h) return fail(G16_ERR_OOM);
+        *out = h;
+        return G16_OK;
+    }
+
+    // ---------------------------------------------------------------------------------------
+    static int stage_assignment(g16_ctx* ctx, const uint64_t* z, uint64_t n_assign, int on_device, const Fr** d_z) {
+        if (on_device) { *d_z = reinterpret_cast<const Fr*>(z); return G16_OK; }
+        Fr* buf = nullptr;
+        G16_TRY(ctx->arena.alloc_n(n_assign, &buf));
+        G16_HIP_TRY(hipMemcpyAsync(buf, z, n_assign * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        *d_z = buf;
+        return G16_OK;
+    }
+
+    template <class X>
+    static void store_xyzz(uint64_t* dst, const X& p) { memcpy(dst, &p, sizeof(X)); }
+    template <class X>
+    static X load_xyzz(const uint64_t* src) { X p; memcpy(&p, src, sizeof(X)); return p; }
+
+    static int prove_partial(g16_ctx* ctx, const g16_pk* pkh, const g16_circuit* ckh, const uint64_t* z, uint64_t n_assign, int on_device,
+                             int skip_b_g1, g16_partial* out) {
+        const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
+        const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
+        hipStream_t st = ctx->stream;
+        if (n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
+        const uint64_t n = ck->dom->n, nin = ck->num_inputs;
+        const uint64_t m = n_assign - 1, w = n_assign - nin;
+        // the reference slices full_assignment[1..], [num_inputs..] (prover.rs:44-45) and msm_bigint
+        // truncates to the shorter side; a shard must lie inside the scalar vector it indexes
+        if (pk->a_start + pk->a_count > m || pk->l_start + pk->l_count > w || pk->h_start + pk->h_count > n) return G16_ERR_BAD_LENGTH;
+        if (pk->b_g1_start != pk->a_start || pk->b_g1_count != pk->a_count || pk->b_g2_start != pk->a_start ||
+            pk->b_g2_count != pk->a_count)
+            return G16_ERR_BAD_ARG;  // a / b_g1 / b_g2 must be sharded identically (they share one bucket sort)
+        memset(out, 0, sizeof(*out));
+        const double t_begin = now_ms();
+        ctx->arena.reset();
+        const Fr* d_z = nullptr;
+        G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
+
+        // ---- witness map: h = QAP::witness_map_from_matrices (prover.rs:37-42)
+        Fr* d_h = nullptr;
+        G16_TRY(ctx->arena.alloc_n(n, &d_h));
+        G16_TRY(ctx->t_wm.start(st));
+        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, st)));
+        G16_TRY(ctx->t_wm.stop(st));
+
+        // ---- h_acc = msm(h_query, h) (prover.rs:63-66)
+        ScalarSort sort_h, sort_z, sort_l;
+        G1X *ws_h = nullptr, *ws_l = nullptr, *ws_a = nullptr, *ws_b1 = nullptr;
+        G2X* ws_b2 = nullptr;
+        G16_TRY(ctx->t_prep_h.start(st));
+        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, st, &sort_h)));
+        G16_TRY(ctx->t_prep_h.stop(st));
+        G16_TRY(ctx->t_msm[0].start(st));
+        G16_TRY((msm_accumulate<Fq>(pk->h, 0, pk->h_count, sort_h, ctx->arena, st, &ws_h, &ctx->t_bucket[0])));
+        G16_TRY(ctx->t_msm[0].stop(st));
+
+        // ---- assignment = full_assignment[1..] (prover.rs:80-85): one digit/sort pass for a, b_g1, b_g2 (and l)
+        G16_TRY(ctx->t_prep_z.start(st));
+        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, ctx->arena, st, &sort_z)));
+        G16_TRY(ctx->t_prep_z.stop(st));
+
+        // l_aux_acc = msm(l_query, aux) (prover.rs:70-74); aux[j] = assignment[j + nin - 1]
+        const bool l_covered = pk->l_count == 0 || (pk->l_start + nin - 1 >= pk->a_start &&
+                                                    pk->l_start + pk->l_count + nin - 1 <= pk->a_start + pk->a_count);
+        G16_TRY(ctx->t_msm[1].start(st));
+        if (l_covered) {
+            const int64_t shift = (int64_t)pk->a_start - (int64_t)(nin - 1) - (int64_t)pk->l_start;
+            G16_TRY((msm_accumulate<Fq>(pk->l, shift, pk->l_count, sort_z, ctx->arena, st, &ws_l, &ctx->t_bucket[1])));
+        } else {
+            G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, ctx->arena, st, &sort_l)));
+            G16_TRY((msm_accumulate<Fq>(pk->l, 0, pk->l_count, sort_l, ctx->arena, st, &ws_l, &ctx->t_bucket[1])));
+        }
+        G16_TRY(ctx->t_msm[1].stop(st));
+        G16_TRY(ctx->t_msm[2].start(st));
+        G16_TRY((msm_accumulate<Fq>(pk->a, 0, pk->a_count, sort_z, ctx->arena, st, &ws_a, &ctx->t_bucket[2])));  // prover.rs:92
+        G16_TRY(ctx->t_msm[2].stop(st));
+        ctx->t_msm[3].used = false;
+        ctx->t_bucket[3].used = false;
+        if (!skip_b_g1) {  // prover.rs:98-108
+            G16_TRY(ctx->t_msm[3].start(st));
+            G16_TRY((msm_accumulate<Fq>(pk->b_g1, 0, pk->b_g1_count, sort_z, ctx->arena, st, &ws_b1, &ctx->t_bucket[3])));
+            G16_TRY(ctx->t_msm[3].stop(st));
+        }
+        G16_TRY(ctx->t_msm[4].start(st));
+        G16_TRY((msm_accumulate<Fq2>(pk->b_g2, 0, pk->b_g2_count, sort_z, ctx->arena, st, &ws_b2, &ctx->t_bucket[4])));  // prover.rs:113
+        G16_TRY(ctx->t_msm[4].stop(st));
+
+        // ---- window sums -> host, fold
+        const MsmPlan& ph = sort_h.plan;
+        const MsmPlan& pz = sort_z.plan;
+        const MsmPlan& pl = l_covered ? sort_z.plan : sort_l.plan;
+        std::vector<G1X> hws_h(ph.W), hws_l(pl.W), hws_a(pz.W), hws_b1(pz.W);
+        std::vector<G2X> hws_b2(pz.W);
+        G16_HIP_TRY(hipMemcpyAsync(hws_h.data(), ws_h, sizeof(G1X) * ph.W, hipMemcpyDeviceToHost, st));
+        G16_HIP_TRY(hipMemcpyAsync(hws_l.data(), ws_l, sizeof(G1X) * pl.W, hipMemcpyDeviceToHost, st));
+        G16_HIP_TRY(hipMemcpyAsync(hws_a.data(), ws_a, sizeof(G1X) * pz.W, hipMemcpyDeviceToHost, st));
+        if (!skip_b_g1) G16_HIP_TRY(hipMemcpyAsync(hws_b1.data(), ws_b1, sizeof(G1X) * pz.W, hipMemcpyDeviceToHost, st));
+        G16_HIP_TRY(hipMemcpyAsync(hws_b2.data(), ws_b2, sizeof(G2X) * pz.W, hipMemcpyDeviceToHost, st));
+        G16_HIP_TRY(hipStreamSynchronize(st));
+        const double t_fold = now_ms();
+        store_xyzz(out->h, fold_windows<Fq>(hws_h.data(), ph));
+        store_xyzz(out->l, fold_windows<Fq>(hws_l.data(), pl));
+        store_xyzz(out->a, fold_windows<Fq>(hws_a.data(), pz));
+        if (!skip_b_g1) store_xyzz(out->b_g1, fold_windows<Fq>(hws_b1.data(), pz));
+        else store_xyzz(out->b_g1, G1X::identity());
+        store_xyzz(out->b_g2, fold_windows<Fq2>(hws_b2.data(), pz));
+        const double t_end = now_ms();
+
+        g16_timings& tm = ctx->tm;
+        memset(&tm, 0, sizeof(tm));
+        tm.witness_map_ms = ctx->t_wm.ms();
+        tm.scalar_prep_ms = ctx->t_prep_h.ms() + ctx->t_prep_z.ms();
+        tm.msm_h_ms = ctx->t_msm[0].ms();
+        tm.msm_l_ms = ctx->t_msm[1].ms();
+        tm.msm_a_ms = ctx->t_msm[2].ms();
+        tm.msm_b_g1_ms = ctx->t_msm[3].ms();
+        tm.msm_b_g2_ms = ctx->t_msm[4].ms();
+        for (int i = 0; i < 5; ++i) tm.bucket_pass_ms += ctx->t_bucket[i].ms();
+        tm.finish_ms = t_end - t_fold;
+        tm.total_ms = t_end - t_begin;
+        return G16_OK;
+    }
+
+    // prover.rs:76-131 glue over the summed MSM results
+    static int prove_finalize(g16_ctx* ctx, const g16_pk* pkh, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
+                              g16_proof* out) {
+        const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
+        if (n_parts < 1) return G16_ERR_BAD_ARG;
+        const double t0 = now_ms();
+        G1X h_acc = G1X::identity(), l_acc = G1X::identity(), a_msm = G1X::identity(), b1_msm = G1X::identity();
+        G2X b2_msm = G2X::identity();
+        for (int i = 0; i < n_parts; ++i) {
+            h_acc.add(load_xyzz<G1X>(parts[i].h));
+            l_acc.add(load_xyzz<G1X>(parts[i].l));
+            a_msm.add(load_xyzz<G1X>(parts[i].a));
+            b1_msm.add(load_xyzz<G1X>(parts[i].b_g1));
+            b2_msm.add(load_xyzz<G2X>(parts[i].b_g2));
+        }
+        const Fr r = load_pod<Fr>(r_), s = load_pod<Fr>(s_);
+        uint32_t rk[Fr::N], sk[Fr::N], rsk[Fr::N];
+        r.to_canonical(rk);
+        s.to_canonical(sk);
+        (r * s).to_canonical(rsk);
+        const int nb = Fr::Params::BITS;
+        const G1X delta1 = G1X::from_affine(pk->delta_g1);
+        const G1X r_s_delta_g1 = delta1.mul_bits(rsk, nb);                      // :76
+        // g_a = r*delta_g1 + a_query[0] + msm + alpha_g1   (calculate_coeff, :90-92, :252-270)
+        G1X g_a = delta1.mul_bits(rk, nb);
+        g_a.add_affine(pk->a_query0);
+        g_a.add(a_msm);
+        g_a.add_affine(pk->alpha_g1);
+        const G1X s_g_a = g_a.mul_bits(sk, nb);                                 // :94
+        G1X g1_b = G1X::identity();
+        if (!r.is_zero()) {                                                    // :98-108
+            g1_b = delta1.mul_bits(sk, nb);
+            g1_b.add_affine(pk->b_g1_query0);
+            g1_b.add(b1_msm);
+            g1_b.add_affine(pk->beta_g1);
+        }
+        G2X g2_b = G2X::from_affine(pk->delta_g2).mul_bits(sk, nb);             // :112-113
+        g2_b.add_affine(pk->b_g2_query0);
+        g2_b.add(b2_msm);
+        g2_b.add_affine(pk->beta_g2);
+        const G1X r_g1_b = g1_b.mul_bits(rk, nb);                               // :114
+        G1X g_c = s_g_a;                                                        // :119-124
+        g_c.add(r_g1_b);
+        g_c.add(r_s_delta_g1.neg());
+        g_c.add(l_acc);
+        g_c.add(h_acc);
+        const G1A pa = g_a.to_affine();                                         // :127-131
+        const G2A pb = g2_b.to_affine();
+        const G1A pc = g_c.to_affine();
+        memset(out, 0, sizeof(*out));
+        memcpy(out->a, &pa, sizeof(pa));
+        memcpy(out->b, &pb, sizeof(pb));
+        memcpy(out->c, &pc, sizeof(pc));
+        const double dt = now_ms() - t0;
+        ctx->tm.finish_ms += dt;
+        ctx->tm.total_ms += dt;
+        return G16_OK;
+    }
+
+    // ---------------------------------------------------------------------------------------
+    static int witness_map_api(g16_ctx* ctx, const g16_circuit* ckh, const uint64_t* z, uint64_t n_assign, int on_device, uint64_t* h_out) {
+        const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
+        if (n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
+        ctx->arena.reset();
+        const Fr* d_z = nullptr;
+        G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
+        Fr* d_h = nullptr;
+        G16_TRY(ctx->arena.alloc_n(ck->dom->n, &d_h));
+        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, ctx->stream)));
+        G16_HIP_TRY(hipMemcpyAsync(h_out, d_h, ck->dom->n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        G16_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return G16_OK;
+    }
+
+    template <class F>
+    static int msm_api(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine) {
+        typedef Affine<F> A;
+        typedef XYZZ<F> X;
+        hipStream_t st = ctx->stream;
+        ctx->arena.reset();
+        A* d_b = nullptr;
+        Fr* d_s = nullptr;
+        G16_TRY(ctx->arena.alloc_n(n ? n : 1, &d_b));
+        G16_TRY(ctx->arena.alloc_n(n ? n : 1, &d_s));
+        if (n) {
+            G16_HIP_TRY(hipMemcpyAsync(d_b, bases, n * sizeof(A), hipMemcpyHostToDevice, st));
+            G16_HIP_TRY(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
+        }
+        ScalarSort ss;
+        G16_TRY((sort_scalars<C>(d_s, n, ctx->arena, st, &ss)));
+        X* ws = nullptr;
+        G16_TRY((msm_accumulate<F>(d_b, 0, n, ss, ctx->arena, st, &ws, &ctx->t_bucket[0])));
+        std::vector<X> hws(ss.plan.W);
+        G16_HIP_TRY(hipMemcpyAsync(hws.data(), ws, sizeof(X) * ss.plan.W, hipMemcpyDeviceToHost, st));
+        G16_HIP_TRY(hipStreamSynchronize(st));
+        const A res = fold_windows<F>(hws.data(), ss.plan).to_affine();
+        memcpy(out_affine, &res, sizeof(A));
+        ctx->tm.bucket_pass_ms = ctx->t_bucket[0].ms();
+        return G16_OK;
+    }
+
+    static int ntt_api(g16_ctx* ctx, uint64_t* data, int log_n, int inverse, int coset) {
+        if (log_n < 0 || log_n > 30) return G16_ERR_DEGREE_TOO_LARGE;
+        hipStream_t st = ctx->stream;
+        Domain<C>* dom = nullptr;
+        G16_TRY((domain_create<C>(log_n, st, &dom)));
+        const size_t n = dom->n;
+        ctx->arena.reset();
+        Fr *d_a = nullptr, *d_o = nullptr;
+        int rc = G16_OK;
+        auto body = [&]() -> int {
+            G16_TRY(ctx->arena.alloc_n(n, &d_a));
+            G16_TRY(ctx->arena.alloc_n(n, &d_o));
+            G16_HIP_TRY(hipMemcpyAsync(d_a, data, n * sizeof(Fr), hipMemcpyHostToDevice, st));
+            if (!inverse) {
+                if (coset) {
+                    G16_TRY((domain_ensure_gpow<C>(dom, st)));
+                    G16_TRY((scale_by_table<C>(d_a, dom->g_pow, n, st)));
+                }
+                G16_TRY((ntt_dif<C>(dom, d_a, false, st)));
+                G16_TRY((bitrev_scale<C>(dom, d_o, d_a, nullptr, nullptr, st)));
+            } else {
+                G16_TRY((ntt_dif<C>(dom, d_a, true, st)));
+                if (coset) G16_TRY((bitrev_scale<C>(dom, d_o, d_a, dom->s2, nullptr, st)));
+                else G16_TRY((bitrev_scale<C>(dom, d_o, d_a, nullptr, &dom->n_inv, st)));
+            }
+            G16_HIP_TRY(hipMemcpyAsync(data, d_o, n * sizeof(Fr), hipMemcpyDeviceToHost, st));
+            G16_HIP_TRY(hipStreamSynchronize(st));
+            return G16_OK;
+        };
+        rc = body();
+        domain_destroy<C>(dom);
+        return rc;
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // host-side hooks (no GPU)
+    template <class F>
+    static int field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+        F x = load_pod<F>(a), y = b ? load_pod<F>(b) : F::zero(), r;
+        switch (op) {
+            case 0: r = x + y; break;
+            case 1: r = x - y; break;
+            case 2: r = x * y; break;
+            case 3: r = x.inverse(); break;
+            case 4: x.to_canonical(r.v); break;
+            case 5: r = F::from_canonical(x.v); break;
+            default: return G16_ERR_BAD_ARG;
+        }
+        memcpy(out, &r, sizeof(F));
+        return G16_OK;
+    }
+    template <class F>
+    static int group_op(int op, const uint64_t* p_, const uint64_t* q_, uint64_t* out) {
+        typedef Affine<F> A;
+        typedef XYZZ<F> X;
+        const A p = load_pod<A>(p_);
+        X acc = X::from_affine(p);
+        if (op == 0) {
+            acc.add_affine(load_pod<A>(q_));
+        } else if (op == 1) {
+            uint32_t k[8];
+            memcpy(k, q_, 32);
+            acc = acc.mul_bits(k, 256);
+        } else if (op == 2) {
+            // exercise the projective + projective path with non-trivial ZZ on both sides
+            X q = X::from_affine(load_pod<A>(q_));
+            X p2 = acc.dbl(), q2 = q.dbl();   // 2p, 2q
+            p2.add(q2);                       // 2p + 2q
+            X np = acc.neg();
+            p2.add(np);                       // p + 2q
+            X nq = q.neg();
+            p2.add(nq);                       // p + q
+            acc = p2;
+        } else {
+            return G16_ERR_BAD_ARG;
+        }
+        const A r = acc.to_affine();
+        memcpy(out, &r, sizeof(A));
+        return G16_OK;
+    }
+    // CPU model of kernels 1-7 of msm.hip: same plan, same digit/bucket/sign mapping, same chunked
+    // running-sum reduction and window fold.
+    template <class F>
+    static int msm_model(const uint64_t* bases_, const uint64_t* scalars_, uint64_t n, int c_override, uint64_t* out) {
+        typedef Affine<F> A;
+        typedef XYZZ<F> X;
+        uint32_t modw[Fr::N];
+        for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
+        MsmPlan plan;
+        if (c_override > 0) {
+            char buf[16];
+            snprintf(buf, sizeof(buf), "%d", c_override);
+            setenv("G16_MSM_WINDOW", buf, 1);
+        }
+        int rc = make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, &plan);
+        if (c_override > 0) unsetenv("G16_MSM_WINDOW");
+        if (rc) return rc;
+        const A* bases = reinterpret_cast<const A*>(bases_);
+        std::vector<X> buckets((size_t)plan.W * plan.B, X::identity());
+        for (uint64_t i = 0; i < n; ++i) {
+            Fr s;
+            memcpy(&s, scalars_ + 4 * i, sizeof(Fr));
+            uint32_t can[Fr::N], sp[MSM_SWORDS];
+            s.to_canonical(can);
+            uint64_t carry = 0;
+            for (int k = 0; k < 10; ++k) {
+                carry += (uint64_t)(k < Fr::N ? can[k] : 0u) + plan.K[k];
+                sp[k] = (uint32_t)carry;
+                carry >>= 32;
+            }
+            sp[10] = 0;
+            A p;
+            memcpy(&p, bases + i, sizeof(A));
+            for (int w = 0; w < plan.W; ++w) {
+                uint32_t bucket, neg;
+                if (!digit_to_bucket(window_raw(sp, w, plan.c), plan.c, &bucket, &neg)) continue;
+                A q = p;
+                if (neg) q.y = q.y.neg();
+                buckets[(size_t)w * plan.B + bucket].add_affine(q);
+            }
+        }
+        const uint32_t G = plan.B >= 32 ? 32u : plan.B, cpw = plan.B / G;
+        std::vector<X> wsum(plan.W, X::identity());
+        for (int w = 0; w < plan.W; ++w) {
+            for (uint32_t ch = 0; ch < cpw; ++ch) {
+                const uint32_t b_lo = ch * G;
+                X run = X::identity(), tot = X::identity();
+                for (uint32_t bb = G; bb-- > 0;) {
+                    run.add(buckets[(size_t)w * plan.B + b_lo + bb]);
+                    tot.add(run);
+                }
+                if (b_lo) {
+                    uint32_t kk[1] = {b_lo};
+                    int nb = 0;
+                    while ((b_lo >> nb) != 0) ++nb;
+                    X mm = run.mul_bits(kk, nb);
+                    tot.add(mm);
+                }
+                wsum[w].add(tot);
+            }
+        }
+        const A res = fold_windows<F>(wsum.data(), plan).to_affine();
+        memcpy(out, &res, sizeof(A));
+        return G16_OK;
+    }
+};
+
+}  // namespace
+
+#define G16_DISPATCH(curve, EXPR)                                             \
+    do {                                                                      \
+        try {                                                                 \
+            if ((curve) == G16_BLS12_381) { typedef Impl<Bls12_381> I; return EXPR; } \
+            if ((curve) == G16_BN254) { typedef Impl<Bn254> I; return EXPR; }  \
+            return G16_ERR_BAD_ARG;                                           \
+        } catch (const std::bad_alloc&) {                                     \
+            return G16_ERR_OOM;                                               \
+        } catch (...) {                                                       \
+            return G16_ERR_INTERNAL;                                          \
+        }                                                                     \
+    } while (0)
+
+extern "C" {
+
+int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
+    if (!out || (curve != G16_BLS12_381 && curve != G16_BN254)) return G16_ERR_BAD_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        g_last_error = "no HIP device visible (the prover has no CPU fallback)";
+        return G16_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= count) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(device_id));
+    g16_ctx* c = new (std::nothrow) g16_ctx();
+    if (!c) return G16_ERR_OOM;
+    c->curve = curve;
+    c->device = device_id;
+    memset(&c->tm, 0, sizeof(c->tm));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return G16_ERR_HIP;
+    }
+    *out = c;
+    return G16_OK;
+}
+
+void g16_ctx_destroy(g16_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->arena.release();
+    ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy();
+    for (int i = 0; i < 5; ++i) { ctx->t_msm[i].destroy(); ctx->t_bucket[i].destroy(); }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void* g16_ctx_stream(g16_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
+    if (!ctx || !view || !out) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::pk_load(ctx, view, out));
+}
+
+void g16_pk_free(g16_pk* pk) {
+    if (!pk) return;
+    (void)hipSetDevice(pk->ctx->device);
+    if (pk->curve == G16_BLS12_381) Impl<Bls12_381>::pk_free(static_cast<DevicePk<Bls12_381>*>(pk->dp));
+    else Impl<Bn254>::pk_free(static_cast<DevicePk<Bn254>*>(pk->dp));
+    delete pk;
+}
+
+int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints, uint64_t num_variables,
+                     g16_circuit** out) {
+    if (!ctx || !abc || !out) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::circuit_load(ctx, abc, num_inputs, num_constraints, num_variables, out));
+}
+
+void g16_circuit_free(g16_circuit* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    if (c->curve == G16_BLS12_381) Impl<Bls12_381>::circuit_free(static_cast<DeviceCircuit<Bls12_381>*>(c->dc));
+    else Impl<Bn254>::circuit_free(static_cast<DeviceCircuit<Bn254>*>(c->dc));
+    delete c;
+}
+
+uint64_t g16_circuit_domain_size(const g16_circuit* c) { return c ? c->domain_size : 0; }
+
+int g16_prove_partial(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
+                      int assignment_on_device, int skip_b_g1, g16_partial* out) {
+    if (!ctx || !pk || !circuit || !full_assignment || !out) return G16_ERR_BAD_ARG;
+    if (pk->curve != ctx->curve || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, out));
+}
+
+int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts, int n_parts, const uint64_t r[4], const uint64_t s[4],
+                       g16_proof* out) {
+    if (!ctx || !pk || !parts || !r || !s || !out) return G16_ERR_BAD_ARG;
+    if (pk->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    G16_DISPATCH(ctx->curve, I::prove_finalize(ctx, pk, parts, n_parts, r, s, out));
+}
+
+int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
+              int assignment_on_device, const uint64_t r[4], const uint64_t s[4], g16_proof* out) {
+    if (!r || !s || !out) return G16_ERR_BAD_ARG;
+    g16_partial part;
+    const uint64_t zero[4] = {0, 0, 0, 0};
+    const int skip_b_g1 = memcmp(r, zero, 32) == 0;  // r == 0 skips B in G1 (prover.rs:98)
+    int rc = g16_prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, &part);
+    if (rc) return rc;
+    return g16_prove_finalize(ctx, pk, &part, 1, r, s, out);
+}
+
+int g16_get_timings(g16_ctx* ctx, g16_timings* out) {
+    if (!ctx || !out) return G16_ERR_BAD_ARG;
+    *out = ctx->tm;
+    return G16_OK;
+}
+
+int g16_witness_map(g16_ctx* ctx, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign, int on_device,
+                    uint64_t* h_out) {
+    if (!ctx || !circuit || !full_assignment || !h_out || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::witness_map_api(ctx, circuit, full_assignment, n_assign, on_device, h_out));
+}
+
+int g16_msm_g1(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine) {
+    if (!ctx || !out_affine || (n && (!bases || !scalars))) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::template msm_api<typename I::Fq>(ctx, bases, scalars, n, out_affine));
+}
+
+int g16_msm_g2(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine) {
+    if (!ctx || !out_affine || (n && (!bases || !scalars))) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::template msm_api<typename I::Fq2>(ctx, bases, scalars, n, out_affine));
+}
+
+int g16_ntt(g16_ctx* ctx, uint64_t* data, int log_n, int inverse, int coset) {
+    if (!ctx || !data) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::ntt_api(ctx, data, log_n, inverse, coset));
+}
+
+int g16_synth_bases(g16_ctx* ctx, int g2, uint64_t seed, uint64_t first, uint64_t n, uint64_t* out_dev) {
+    if (!ctx || (n && !out_dev)) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    if (ctx->curve == G16_BLS12_381) rc = synth_bases_device<Bls12_381>(g2, seed, first, n, out_dev, ctx->stream);
+    else rc = synth_bases_device<Bn254>(g2, seed, first, n, out_dev, ctx->stream);
+    if (rc) return rc;
+    G16_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return G16_OK;
+}
+
+int g16_host_field_op(int curve, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    if (!a || !out) return G16_ERR_BAD_ARG;
+    if (which == 0) G16_DISPATCH(curve, I::template field_op<typename I::Fr>(op, a, b, out));
+    G16_DISPATCH(curve, I::template field_op<typename I::Fq>(op, a, b, out));
+}
+
+int g16_host_group_op(int curve, int g2, int op, const uint64_t* p, const uint64_t* q_or_k, uint64_t* out) {
+    if (!p || !q_or_k || !out) return G16_ERR_BAD_ARG;
+    if (!g2) G16_DISPATCH(curve, I::template group_op<typename I::Fq>(op, p, q_or_k, out));
+    G16_DISPATCH(curve, I::template group_op<typename I::Fq2>(op, p, q_or_k, out));
+}
+
+int g16_host_msm_model(int curve, int g2, const uint64_t* bases, const uint64_t* scalars, uint64_t n, int c, uint64_t* out_affine) {
+    if (!out_affine || (n && (!bases || !scalars))) return G16_ERR_BAD_ARG;
+    if (!g2) G16_DISPATCH(curve, I::template msm_model<typename I::Fq>(bases, scalars, n, c, out_affine));
+    G16_DISPATCH(curve, I::template msm_model<typename I::Fq2>(bases, scalars, n, c, out_affine));
+}
+
+const char* g16_strerror(int status) {
+    switch (status) {
+        case G16_OK: return "ok";
+        case G16_ERR_DEGREE_TOO_LARGE: return "polynomial degree too large for the scalar field's 2-adicity";
+        case G16_ERR_BAD_LENGTH: return "assignment / proving key / matrix length mismatch";
+        case G16_ERR_BAD_ARG: return "bad argument";
+        case G16_ERR_HIP: return "HIP runtime error (see g16_last_error)";
+        case G16_ERR_OOM: return "out of memory";
+        case G16_ERR_NO_DEVICE: return "no HIP device";
+        case G16_ERR_INTERNAL: return "internal error";
+        default: return "unknown status";
+    }
+}
+
+const char* g16_last_error(void) { return g_last_error.c_str(); }
+const char* g16_version(void) { return "g16_mi355x 0.1 (gfx950)"; }
+
+}  // extern "C"

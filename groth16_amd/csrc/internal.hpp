@@ -1,0 +1,143 @@
+// Internal plumbing shared by the translation units of libg16_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/g16_mi355x.h"
+#include "curve.hpp"
+
+namespace g16 {
+
+void set_last_error(const char* what, hipError_t e, const char* file, int line);
+
+#define G16_HIP_TRY(expr)                                                     \
+    do {                                                                      \
+        hipError_t e__ = (expr);                                              \
+        if (e__ != hipSuccess) {                                              \
+            ::g16::set_last_error(#expr, e__, __FILE__, __LINE__);            \
+            return e__ == hipErrorOutOfMemory ? G16_ERR_OOM : G16_ERR_HIP;    \
+        }                                                                     \
+    } while (0)
+
+#define G16_TRY(expr)                  \
+    do {                               \
+        int rc__ = (expr);             \
+        if (rc__ != G16_OK) return rc__; \
+    } while (0)
+
+#define G16_LAUNCH_CHECK() G16_HIP_TRY(hipGetLastError())
+
+// Device scratch arena: chunks are retained across calls (first call pays hipMalloc), offsets
+// reset at the start of each top-level call.  Sized for 288 GB of HBM: nothing is ever freed
+// mid-proof, so there is no hipFree-induced device sync on the hot path.
+struct Arena {
+    struct Chunk { char* p; size_t cap; size_t used; };
+    std::vector<Chunk> chunks;
+    size_t min_chunk = (size_t)256 << 20;
+    void reset() { for (auto& c : chunks) c.used = 0; }
+    int alloc(size_t bytes, void** out);
+    template <class T> int alloc_n(size_t n, T** out) { return alloc(n * sizeof(T), (void**)out); }
+    void release();
+    size_t total() const { size_t t = 0; for (auto& c : chunks) t += c.cap; return t; }
+};
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool used = false;
+    int start(hipStream_t s) {
+        if (!a) { G16_HIP_TRY(hipEventCreate(&a)); G16_HIP_TRY(hipEventCreate(&b)); }
+        used = true;
+        G16_HIP_TRY(hipEventRecord(a, s));
+        return G16_OK;
+    }
+    int stop(hipStream_t s) { G16_HIP_TRY(hipEventRecord(b, s)); return G16_OK; }
+    double ms() {
+        if (!used) return 0.0;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, a, b) != hipSuccess) return 0.0;
+        return (double)t;
+    }
+    void destroy() { if (a) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); a = b = nullptr; } }
+};
+
+// ---- NTT domain (ntt.hip) ---------------------------------------------------------------
+template <class C>
+struct Domain {
+    typedef typename C::Fr Fr;
+    int log_n = 0;
+    size_t n = 0;
+    Fr* tw_fwd = nullptr;    // w^k,  k < n/2
+    Fr* tw_inv = nullptr;    // w^-k, k < n/2
+    Fr* s1_br = nullptr;     // n^-1 * g^bitrev(i)   (between inverse-DIF and coset-DIT)
+    Fr* s2 = nullptr;        // n^-1 * g^-k          (after the final inverse-DIF, natural index)
+    Fr* g_pow = nullptr;     // g^k natural          (unit-level coset fft only; lazily built)
+    Fr n_inv, zinv;          // 1/n ; 1/(g^n - 1)
+};
+template <class C> int domain_create(int log_n, hipStream_t st, Domain<C>** out);
+template <class C> void domain_destroy(Domain<C>* d);
+template <class C> int domain_ensure_gpow(Domain<C>* d, hipStream_t st);
+
+// in-place passes over n = 2^log_n elements on device
+// natural -> bit-reversed (Gentleman-Sande), roots = d->tw_inv if inverse else d->tw_fwd, no scaling
+template <class C> int ntt_dif(const Domain<C>* d, typename C::Fr* data, bool inverse, hipStream_t st);
+// bit-reversed -> natural (Cooley-Tukey); each input element is first multiplied by prescale[i] if non-null
+template <class C> int ntt_dit(const Domain<C>* d, typename C::Fr* data, bool inverse, const typename C::Fr* prescale, hipStream_t st);
+// out[k] = in[bitrev(k)] * table[k] * cst  (table may be null; has_cst selects the constant factor)
+template <class C> int bitrev_scale(const Domain<C>* d, typename C::Fr* out, const typename C::Fr* in, const typename C::Fr* table,
+                                    const typename C::Fr* cst, hipStream_t st);
+template <class C> int scale_by_table(typename C::Fr* data, const typename C::Fr* table, size_t n, hipStream_t st);
+
+// ---- R1CS on device + witness map (witness_map.hip) -------------------------------------------
+template <class C>
+struct DeviceCircuit {
+    typedef typename C::Fr Fr;
+    uint64_t num_inputs = 0, num_constraints = 0, num_variables = 0;
+    uint64_t* row_ptr[3] = {nullptr, nullptr, nullptr};
+    uint32_t* col[3] = {nullptr, nullptr, nullptr};
+    Fr* val[3] = {nullptr, nullptr, nullptr};
+    uint64_t nnz[3] = {0, 0, 0};
+    Domain<C>* dom = nullptr;
+};
+// d_z: full assignment on device; d_h: n Fr out (natural order).  Scratch comes from the arena.
+template <class C> int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, typename C::Fr* d_h, Arena& arena,
+                                          hipStream_t st);
+
+// ---- MSM (msm.hip) ----------------------------------------------------------------------------
+struct MsmPlan {
+    int c = 0;          // window bits (<= 16)
+    int W = 0;          // windows
+    uint32_t B = 0;     // buckets per window = 2^(c-1)
+    uint32_t Lmax = 0;  // max sorted entries one accumulation task walks
+    uint32_t chunk = 0; // points per histogram/scatter block
+    uint32_t K[10];     // signed-digit bias  sum_w 2^(c-1) 2^(cw)
+};
+int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, MsmPlan* plan);
+int msm_window_override();  // env G16_MSM_WINDOW (0 = auto)
+
+// digit extraction + bucket sort of one scalar array, shared by every MSM over those scalars
+struct ScalarSort {
+    MsmPlan plan;
+    uint64_t n = 0;
+    uint32_t* sorted = nullptr;    // [<= n*W] point index | sign<<31, grouped by (window, bucket)
+    uint32_t* offsets = nullptr;   // [W*B + 1] exclusive prefix of bucket sizes
+    uint32_t* task_off = nullptr;  // [W*B + 1] exclusive prefix of per-bucket task counts
+    uint32_t max_tasks = 0;        // host-side upper bound on task_off[W*B]
+};
+template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipStream_t st, ScalarSort* out);
+
+// Pippenger over one base array using a ScalarSort.  Sorted index p addresses bases[p + shift]
+// when 0 <= p + shift < base_count (other entries are skipped: lets l_query reuse the sort made
+// for a/b).  Writes the W per-window sums (XYZZ) to host memory `window_sums` after a stream sync
+// is issued by the caller; d_window_sums is arena memory.
+template <class F> int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena,
+                                      hipStream_t st, XYZZ<F>** d_window_sums, EventTimer* bucket_timer);
+// host: sum_w 2^(c w) R_w
+template <class F> XYZZ<F> fold_windows(const XYZZ<F>* window_sums, const MsmPlan& plan);
+
+// ---- synthetic generators (synth.hip) -----------------------------------------------------------
+template <class C> int synth_bases_device(int g2, uint64_t seed, uint64_t first, uint64_t n, void* out_dev, hipStream_t st);
+
+}  // namespace g16

@@ -1,0 +1,422 @@
+// Variable-base multi-scalar multiplication (Pippenger bucket method) for gfx950.
+//
+// Replaces ark-ec's VariableBaseMSM::msm_bigint at its five call sites in the prover
+// (/root/reference/src/prover.rs:66, 74 and 262 via calculate_coeff :92,105,113).
+// The reference runs one serial bucket scan per window, windows in parallel (<= 17-way); the
+// result of an MSM is a canonical group element, so the GPU is free to organise the work
+// differently:
+//
+//   1. digits_kernel        scalars (Montgomery Fr) -> canonical (prover.rs:63-65 into_bigint)
+//                           -> biased signed digits, written as W coalesced u16 "digit planes"
+//   2. bucket_count_kernel  per (point-chunk, window) workgroup: LDS-resident bucket histogram
+//                           (2^(c-1) counters, <= 128 KiB of the 160 KiB LDS) flushed with one
+//                           global atomic per non-empty bucket
+//   3. bucket_scan_kernel   exclusive prefix sums: bucket offsets and task offsets
+//   4. bucket_scatter_kernel  same LDS histogram, then one global atomic per bucket reserves a
+//                           slice and LDS atomics hand out the slots: a counting sort of
+//                           (point index | sign) by (window, bucket) -- order inside a bucket is
+//                           irrelevant because group addition commutes
+//   5. bucket_accumulate_kernel  THE hot kernel: one lane per task (a run of <= Lmax sorted
+//                           entries of one bucket) gathers affine bases (96 B / 192 B each)
+//                           and folds them with XYZZ mixed additions (8M+2S, no inversion)
+//   6. bucket_reduce_kernel / window_reduce_kernel   sum_b (b+1) S_b by chunked running sums
+//   7. host                 sum_w 2^(cw) R_w  (<= 256 doublings)
+//
+// Steps 1-4 depend only on the scalars and are shared by every MSM over the same scalar
+// vector (a_query, b_g1_query, b_g2_query and l_query all use the witness: one sort, four
+// accumulations).
+// Roofline: step 5 reads N*W*(sizeof(Affine)+4) bytes but spends ~10 field products
+// (~3000 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
+// bytes/s it sustains is reported against the 8 TB/s roofline by bench.py regardless.
+#include "internal.hpp"
+#include "msm_common.hpp"
+#include <cstdlib>
+
+namespace g16 {
+
+static constexpr int SORT_THREADS = 1024;
+static constexpr int ACC_THREADS = 128;
+static constexpr int RED_THREADS = 64;
+
+struct PlanDev {
+    int c, W;
+    uint32_t B;
+    uint32_t K[10];
+};
+
+// ---------------------------------------------------------------------------------------------
+// 1. digit planes
+// ---------------------------------------------------------------------------------------------
+template <class Fr>
+__global__ __launch_bounds__(256) void digits_kernel(const Fr* __restrict__ scalars, uint64_t n, PlanDev plan,
+                                                     uint16_t* __restrict__ planes) {
+    __shared__ uint32_t sw[MSM_SWORDS][256];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[Fr::N];
+    scalars[i].to_canonical(s);
+    uint64_t carry = 0;
+    G16_UNROLL for (int k = 0; k < 10; ++k) {
+        carry += (uint64_t)(k < Fr::N ? s[k] : 0u) + plan.K[k];
+        sw[k][threadIdx.x] = (uint32_t)carry;
+        carry >>= 32;
+    }
+    sw[10][threadIdx.x] = 0;
+    // each thread reads back only its own column: no barrier needed
+    for (int w = 0; w < plan.W; ++w) {
+        const int bit = w * plan.c, word = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)sw[word][threadIdx.x] | ((uint64_t)sw[word + 1][threadIdx.x] << 32);
+        planes[(uint64_t)w * n + i] = (uint16_t)((uint32_t)(two >> sh) & ((1u << plan.c) - 1u));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. histogram   grid = (chunks, W)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const uint16_t* __restrict__ planes, uint64_t n, uint32_t chunk,
+                                                                    int c, uint32_t B, uint32_t* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    const int w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) hist[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const uint16_t* plane = planes + (uint64_t)w * n;
+    for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS) {
+        uint32_t bucket, neg;
+        if (digit_to_bucket(plane[p], c, &bucket, &neg)) atomicAdd(&hist[bucket], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = counts + (uint64_t)w * B;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
+        const uint32_t v = hist[b];
+        if (v) atomicAdd(&out[b], v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. scan (single workgroup; M = W*B <= 2^19 entries)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* __restrict__ counts, uint32_t M, uint32_t lmax_log,
+                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ task_off) {
+    __shared__ uint32_t sa[1024], sb[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t seg = (M + 1023) / 1024;
+    const uint32_t lo = min(M, tid * seg), hi = min(M, lo + seg);
+    const uint32_t lmask = (1u << lmax_log) - 1u;
+    uint32_t sumA = 0, sumB = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t v = counts[i];
+        sumA += v;
+        sumB += (v + lmask) >> lmax_log;
+    }
+    sa[tid] = sumA;
+    sb[tid] = sumB;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t va = tid >= d ? sa[tid - d] : 0u, vb = tid >= d ? sb[tid - d] : 0u;
+        __syncthreads();
+        sa[tid] += va;
+        sb[tid] += vb;
+        __syncthreads();
+    }
+    uint32_t baseA = sa[tid] - sumA, baseB = sb[tid] - sumB;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t v = counts[i];
+        offsets[i] = baseA;
+        task_off[i] = baseB;
+        baseA += v;
+        baseB += (v + lmask) >> lmax_log;
+    }
+    if (tid == 1023) {
+        offsets[M] = sa[1023];
+        task_off[M] = sb[1023];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. scatter   grid = (chunks, W)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(const uint16_t* __restrict__ planes, uint64_t n, uint32_t chunk,
+                                                                      int c, uint32_t B, const uint32_t* __restrict__ offsets,
+                                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    const int w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) hist[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const uint16_t* plane = planes + (uint64_t)w * n;
+    for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS) {
+        uint32_t bucket, neg;
+        if (digit_to_bucket(plane[p], c, &bucket, &neg)) atomicAdd(&hist[bucket], 1u);
+    }
+    __syncthreads();
+    // reserve a slice of every non-empty bucket; hist[b] becomes this block's write cursor
+    const uint64_t wb = (uint64_t)w * B;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
+        const uint32_t v = hist[b];
+        if (v) hist[b] = offsets[wb + b] + atomicAdd(&cursor[wb + b], v);
+    }
+    __syncthreads();
+    for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS) {
+        uint32_t bucket, neg;
+        if (digit_to_bucket(plane[p], c, &bucket, &neg)) {
+            const uint32_t pos = atomicAdd(&hist[bucket], 1u);
+            sorted[pos] = (uint32_t)p | (neg << 31);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5. bucket accumulation -- one lane per task
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate_kernel(const Affine<F>* __restrict__ bases, int64_t shift,
+                                                                        uint64_t base_count, const uint32_t* __restrict__ sorted,
+                                                                        const uint32_t* __restrict__ offsets,
+                                                                        const uint32_t* __restrict__ task_off, uint32_t M,
+                                                                        uint32_t lmax_log, XYZZ<F>* __restrict__ partials) {
+    const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
+    const uint32_t ntasks = task_off[M];
+    if (t >= ntasks) return;
+    uint32_t lo = 0, hi = M;  // task_off[lo] <= t < task_off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (task_off[mid] <= t) lo = mid; else hi = mid;
+    }
+    const uint32_t k = t - task_off[lo];
+    const uint32_t start = offsets[lo] + (k << lmax_log);
+    const uint32_t end = min(offsets[lo + 1], start + (1u << lmax_log));
+    XYZZ<F> acc = XYZZ<F>::identity();
+    for (uint32_t e = start; e < end; ++e) {
+        const uint32_t v = sorted[e];
+        const int64_t idx = (int64_t)(v & 0x7fffffffu) + shift;
+        if (idx < 0 || (uint64_t)idx >= base_count) continue;
+        Affine<F> p = bases[idx];
+        if (v >> 31) p.y = p.y.neg();
+        acc.add_affine(p);
+    }
+    partials[t] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const XYZZ<F>* __restrict__ partials,
+                                                                    const uint32_t* __restrict__ task_off, uint32_t B, int W,
+                                                                    uint32_t G, XYZZ<F>* __restrict__ chunk_out) {
+    const uint32_t cpw = B / G;
+    const uint32_t t = blockIdx.x * RED_THREADS + threadIdx.x;
+    if (t >= cpw * (uint32_t)W) return;
+    const uint32_t w = t / cpw, ch = t % cpw, b_lo = ch * G;
+    XYZZ<F> run = XYZZ<F>::identity(), tot = XYZZ<F>::identity();
+    for (uint32_t bb = G; bb-- > 0;) {
+        const uint32_t gb = w * B + b_lo + bb;
+        const uint32_t t0 = task_off[gb], t1 = task_off[gb + 1];
+        for (uint32_t q = t0; q < t1; ++q) run.add(partials[q]);
+        tot.add(run);
+    }
+    // sum_b (b+1) S_b over the chunk = tot + b_lo * run
+    if (b_lo) {
+        uint32_t kk[1] = {b_lo};
+        XYZZ<F> m = run.mul_bits(kk, 32 - __clz(b_lo));
+        tot.add(m);
+    }
+    chunk_out[t] = tot;
+}
+
+template <class F>
+__global__ __launch_bounds__(RED_THREADS) void window_reduce_kernel(const XYZZ<F>* __restrict__ chunk_out, uint32_t cpw,
+                                                                    XYZZ<F>* __restrict__ window_sums) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    XYZZ<F> acc = XYZZ<F>::identity();
+    for (uint32_t j = tid; j < cpw; j += RED_THREADS) acc.add(chunk_out[(uint64_t)w * cpw + j]);
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = RED_THREADS / 2; d > 0; d >>= 1) {
+        if (tid < d) {
+            XYZZ<F> a = sh[tid];
+            a.add(sh[tid + d]);
+            sh[tid] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) window_sums[w] = sh[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int msm_window_override() {
+    const char* e = getenv("G16_MSM_WINDOW");
+    return e ? atoi(e) : 0;
+}
+
+int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, MsmPlan* plan) {
+    int lg = 0;
+    while (((uint64_t)2 << lg) <= n) ++lg;  // floor(log2 n), 0 for n <= 1
+    int c = msm_window_override();
+    if (c <= 0) c = lg - 5;
+    if (c < 3) c = 3;
+    if (c > 16) c = 16;
+    int W = (scalar_bits + 1 + c - 1) / c;
+    for (;; ++W) {
+        // K = sum_w 2^(c-1) 2^(cw); need (modulus - 1) + K < 2^(cW) and cW <= 32*10
+        if (c * W > 320) return G16_ERR_INTERNAL;
+        uint32_t K[MSM_SWORDS] = {0};
+        for (int w = 0; w < W; ++w) {
+            const int bit = w * c + c - 1;
+            K[bit >> 5] |= 1u << (bit & 31);
+        }
+        uint32_t sum[MSM_SWORDS];
+        uint64_t carry = 0;
+        for (int k = 0; k < MSM_SWORDS; ++k) {
+            carry += (uint64_t)K[k] + (k < mod_nwords ? modulus_words[k] : 0u);
+            sum[k] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        // sum = modulus + K  >  (modulus - 1) + K ; require sum <= 2^(cW)  (conservative by one)
+        bool ok = true;
+        const int top = c * W;
+        for (int bit = MSM_SWORDS * 32 - 1; bit >= top; --bit)
+            if ((sum[bit >> 5] >> (bit & 31)) & 1) { ok = false; break; }
+        if (ok) {
+            plan->c = c;
+            plan->W = W;
+            plan->B = 1u << (c - 1);
+            for (int k = 0; k < 10; ++k) plan->K[k] = K[k];
+            break;
+        }
+    }
+    // task granularity: ~2x the mean bucket load, power of two, >= 32
+    uint64_t mean = n / plan->B + 1;
+    uint32_t l = 32;
+    while (l < 2 * mean && l < (1u << 20)) l <<= 1;
+    plan->Lmax = l;
+    // histogram / scatter chunking: ~2048 workgroups in total, chunk a multiple of 1024 points
+    uint64_t nchunks = 2048 / (uint64_t)plan->W;
+    if (nchunks < 1) nchunks = 1;
+    uint64_t chunk = (n + nchunks - 1) / nchunks;
+    chunk = (chunk + 1023) / 1024 * 1024;
+    if (chunk < 1024) chunk = 1024;
+    plan->chunk = (uint32_t)chunk;
+    return G16_OK;
+}
+
+static int ilog2(uint32_t v) { int l = 0; while ((1u << l) < v) ++l; return l; }
+
+template <class C>
+int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipStream_t st, ScalarSort* out) {
+    typedef typename C::Fr Fr;
+    if (n >= ((uint64_t)1 << 31)) return G16_ERR_BAD_LENGTH;
+    uint32_t modw[Fr::N];
+    for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
+    MsmPlan plan;
+    G16_TRY(make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, &plan));
+    out->plan = plan;
+    out->n = n;
+    const uint32_t M = plan.B * (uint32_t)plan.W;
+    const uint64_t nw = n * (uint64_t)plan.W;
+    if (nw >= ((uint64_t)1 << 32)) return G16_ERR_BAD_LENGTH;
+    uint16_t* planes = nullptr;
+    uint32_t *counts = nullptr, *cursor = nullptr;
+    G16_TRY(arena.alloc_n(nw ? nw : 1, &planes));
+    G16_TRY(arena.alloc_n((size_t)2 * M, &counts));
+    cursor = counts + M;
+    G16_TRY(arena.alloc_n((size_t)M + 1, &out->offsets));
+    G16_TRY(arena.alloc_n((size_t)M + 1, &out->task_off));
+    G16_TRY(arena.alloc_n(nw ? nw : 1, &out->sorted));
+    out->max_tasks = (uint32_t)(nw / plan.Lmax) + M;
+    G16_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)2 * M * sizeof(uint32_t), st));
+    PlanDev pd;
+    pd.c = plan.c; pd.W = plan.W; pd.B = plan.B;
+    for (int k = 0; k < 10; ++k) pd.K[k] = plan.K[k];
+    const size_t lds = (size_t)plan.B * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        128 * 1024));
+        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        128 * 1024));
+        attr_set = true;
+    }
+    if (n) {
+        hipLaunchKernelGGL((digits_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pd, planes);
+        G16_LAUNCH_CHECK();
+        const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
+                           counts);
+        G16_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, counts, M, (uint32_t)ilog2(plan.Lmax), out->offsets, out->task_off);
+    G16_LAUNCH_CHECK();
+    if (n) {
+        const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
+                           out->offsets, cursor, out->sorted);
+        G16_LAUNCH_CHECK();
+    }
+    return G16_OK;
+}
+
+template <class F>
+int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena, hipStream_t st,
+                   XYZZ<F>** d_window_sums, EventTimer* bucket_timer) {
+    const MsmPlan& plan = ss.plan;
+    const uint32_t M = plan.B * (uint32_t)plan.W;
+    const uint32_t G = plan.B >= 32 ? 32u : plan.B;
+    const uint32_t cpw = plan.B / G;
+    XYZZ<F>*partials = nullptr, *chunk_out = nullptr, *wsum = nullptr;
+    G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
+    G16_TRY(arena.alloc_n((size_t)cpw * plan.W, &chunk_out));
+    G16_TRY(arena.alloc_n((size_t)plan.W, &wsum));
+    if (bucket_timer) G16_TRY(bucket_timer->start(st));
+    if (ss.max_tasks) {
+        hipLaunchKernelGGL((bucket_accumulate_kernel<F>), dim3((ss.max_tasks + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, st,
+                           d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), partials);
+        G16_LAUNCH_CHECK();
+    }
+    if (bucket_timer) G16_TRY(bucket_timer->stop(st));
+    hipLaunchKernelGGL((bucket_reduce_kernel<F>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, partials,
+                       ss.task_off, plan.B, plan.W, G, chunk_out);
+    G16_LAUNCH_CHECK();
+    static bool attr_set = false;
+    const size_t lds = sizeof(XYZZ<F>) * RED_THREADS;
+    if (!attr_set && lds > 48 * 1024) {
+        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_reduce_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((window_reduce_kernel<F>), dim3(plan.W), dim3(RED_THREADS), lds, st, chunk_out, cpw, wsum);
+    G16_LAUNCH_CHECK();
+    *d_window_sums = wsum;
+    return G16_OK;
+}
+
+template <class F>
+XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
+    XYZZ<F> total = XYZZ<F>::identity();
+    for (int w = plan.W - 1; w >= 0; --w) {
+        for (int k = 0; k < plan.c; ++k) total = total.dbl();
+        total.add(ws[w]);
+    }
+    return total;
+}
+
+#define G16_INSTANTIATE_MSM(C)                                                                                               \
+    template int sort_scalars<C>(const typename C::Fr*, uint64_t, Arena&, hipStream_t, ScalarSort*);                        \
+    template int msm_accumulate<typename C::Fq>(const Affine<typename C::Fq>*, int64_t, uint64_t, const ScalarSort&, Arena&, \
+                                                hipStream_t, XYZZ<typename C::Fq>**, EventTimer*);                           \
+    template int msm_accumulate<typename C::Fq2>(const Affine<typename C::Fq2>*, int64_t, uint64_t, const ScalarSort&,      \
+                                                 Arena&, hipStream_t, XYZZ<typename C::Fq2>**, EventTimer*);                 \
+    template XYZZ<typename C::Fq> fold_windows<typename C::Fq>(const XYZZ<typename C::Fq>*, const MsmPlan&);               \
+    template XYZZ<typename C::Fq2> fold_windows<typename C::Fq2>(const XYZZ<typename C::Fq2>*, const MsmPlan&);
+
+G16_INSTANTIATE_MSM(Bls12_381)
+G16_INSTANTIATE_MSM(Bn254)
+
+}  // namespace g16

@@ -1,0 +1,334 @@
+"""Host-side mirror of ark-groth16's prover interface over the C ABI (see package docstring).
+
+Data is held exactly as the Rust side holds it: numpy uint64 arrays of little-endian Montgomery
+limbs (``Fr`` = 4 limbs; ``Fq`` = 6 / 4 limbs for BLS12-381 / BN254), affine points as
+``x|y`` (G1) or ``x.c0 x.c1 y.c0 y.c1`` (G2), the identity as all-zero limbs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import secrets
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .binding import (CURVE_ID, FQ_LIMBS, CsrViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC, lib, ptr32, ptr64, u64p)
+
+_MODULUS_R = {
+    "bls12_381": 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+    "bn254": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+}
+
+
+def _c(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+@dataclass
+class ConstraintMatrices:
+    """ark_relations::r1cs::ConstraintMatrices flattened to CSR (row_ptr u64, col u32, val Fr)."""
+
+    num_instance_variables: int
+    num_witness_variables: int
+    num_constraints: int
+    a: Tuple[np.ndarray, np.ndarray, np.ndarray]
+    b: Tuple[np.ndarray, np.ndarray, np.ndarray]
+    c: Tuple[np.ndarray, np.ndarray, np.ndarray]
+
+    @staticmethod
+    def from_rows(curve: str, num_instance: int, num_witness: int, rows_a, rows_b, rows_c) -> "ConstraintMatrices":
+        """rows: Vec<Vec<(F, usize)>> with F given as 4-limb Montgomery arrays."""
+        def conv(rows):
+            rp = np.zeros(len(rows) + 1, dtype=np.uint64)
+            cols, vals = [], []
+            for i, row in enumerate(rows):
+                for coeff, idx in row:
+                    cols.append(idx)
+                    vals.append(np.asarray(coeff, dtype=np.uint64))
+                rp[i + 1] = len(cols)
+            val = np.stack(vals) if vals else np.zeros((0, 4), dtype=np.uint64)
+            return rp, np.asarray(cols, dtype=np.uint32), _c(val)
+        return ConstraintMatrices(num_instance, num_witness, len(rows_a), conv(rows_a), conv(rows_b), conv(rows_c))
+
+
+@dataclass
+class ProvingKey:
+    """src/data_structures.rs:125-143 (vk fields the prover reads are flattened in)."""
+
+    curve: str
+    alpha_g1: np.ndarray
+    beta_g1: np.ndarray
+    delta_g1: np.ndarray
+    beta_g2: np.ndarray
+    delta_g2: np.ndarray
+    a_query: np.ndarray
+    b_g1_query: np.ndarray
+    b_g2_query: np.ndarray
+    h_query: np.ndarray
+    l_query: np.ndarray
+
+
+@dataclass
+class Proof:
+    """src/data_structures.rs:8-16; affine Montgomery limbs."""
+
+    a: np.ndarray
+    b: np.ndarray
+    c: np.ndarray
+
+    def __eq__(self, o):
+        return (self.a == o.a).all() and (self.b == o.b).all() and (self.c == o.c).all()
+
+    def flat(self) -> np.ndarray:
+        return np.concatenate([self.a, self.b, self.c])
+
+
+class _Ctx:
+    def __init__(self, curve: str, device: int):
+        self.lib = lib()
+        self.curve = curve
+        self.handle = C.c_void_p()
+        self.lib.check(self.lib.c.g16_ctx_create(CURVE_ID[curve], device, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.c.g16_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class _DevicePk:
+    """g16_pk handle; shard = (index, count) splits every MSM base array into contiguous ranges."""
+
+    def __init__(self, ctx: _Ctx, pk: ProvingKey, num_inputs: int, shard: Tuple[int, int] = (0, 1)):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        self._keep = []
+        idx, cnt = shard
+        m = len(pk.a_query) - 1
+
+        def rng(n):
+            lo = n * idx // cnt
+            hi = n * (idx + 1) // cnt
+            return lo, hi
+
+        def q(arr: np.ndarray, skip: int, lo: int, hi: int) -> QueryC:
+            sl = _c(arr[skip + lo: skip + hi])
+            self._keep.append(sl)
+            return QueryC(sl.ctypes.data if len(sl) else None, hi - lo, lo)
+
+        a_lo, a_hi = rng(m)
+        # keep l aligned with a so that the library can reuse one bucket sort (l index j <-> a index j + num_inputs - 1)
+        w = len(pk.l_query)
+        l_lo = min(w, max(0, a_lo - (num_inputs - 1))) if idx else 0
+        l_hi = min(w, max(0, a_hi - (num_inputs - 1))) if idx < cnt - 1 else w
+        h_lo, h_hi = rng(len(pk.h_query))
+        keep = [_c(x).reshape(-1) for x in (pk.alpha_g1, pk.beta_g1, pk.delta_g1, pk.beta_g2, pk.delta_g2, pk.a_query[0],
+                                            pk.b_g1_query[0], pk.b_g2_query[0])]
+        self._keep += keep
+        view = PkViewC(*[ptr64(k) for k in keep], q(pk.a_query, 1, a_lo, a_hi), q(pk.b_g1_query, 1, a_lo, a_hi),
+                       q(pk.b_g2_query, 1, a_lo, a_hi), q(pk.h_query, 0, h_lo, h_hi), q(pk.l_query, 0, l_lo, l_hi), 0)
+        ctx.lib.check(ctx.lib.c.g16_pk_load(ctx.handle, C.byref(view), C.byref(self.handle)))
+        self._keep = []  # the library copied everything
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.c.g16_pk_free(self.handle)
+            self.handle = C.c_void_p()
+
+
+class _DeviceCircuit:
+    def __init__(self, ctx: _Ctx, m: ConstraintMatrices):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        self.num_variables = m.num_instance_variables + m.num_witness_variables
+        views = (CsrViewC * 3)(*[CsrViewC(ptr64(np.ascontiguousarray(x[0], dtype=np.uint64)), ptr32(np.ascontiguousarray(x[1], dtype=np.uint32)),
+                                          ptr64(_c(x[2]))) for x in (m.a, m.b, m.c)])
+        self._keep = (m.a, m.b, m.c)
+        ctx.lib.check(ctx.lib.c.g16_circuit_load(ctx.handle, views, m.num_instance_variables, m.num_constraints, self.num_variables,
+                                                 C.byref(self.handle)))
+
+    @property
+    def domain_size(self) -> int:
+        return int(self.ctx.lib.c.g16_circuit_domain_size(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.c.g16_circuit_free(self.handle)
+            self.handle = C.c_void_p()
+
+
+class LibsnarkReduction:
+    """R1CSToQAP default reduction (src/r1cs_to_qap.rs:123-248), witness side only."""
+
+    @staticmethod
+    def witness_map_from_matrices(prover: "Groth16", matrices: ConstraintMatrices, num_inputs: int, num_constraints: int,
+                                  full_assignment: np.ndarray) -> np.ndarray:
+        return prover.witness_map_from_matrices(matrices, num_inputs, num_constraints, full_assignment)
+
+
+class Groth16:
+    """``Groth16::<E, LibsnarkReduction>`` prover methods for E in {Bls12_381, Bn254} on one MI355X.
+
+    Device-resident copies of proving keys and constraint matrices are cached per object
+    (they are per-circuit constants, like ``&pk`` in the reference)."""
+
+    def __init__(self, curve: str = "bls12_381", device: int = 0):
+        if curve not in CURVE_ID:
+            raise ValueError(f"unsupported curve {curve}")
+        self.curve = curve
+        self._ctx = _Ctx(curve, device)
+        self._pks: Dict[Tuple[int, Tuple[int, int]], _DevicePk] = {}
+        self._cks: Dict[int, _DeviceCircuit] = {}
+
+    # -- handles -------------------------------------------------------------------------
+    def _pk(self, pk: ProvingKey, num_inputs: int, shard=(0, 1)) -> _DevicePk:
+        key = (id(pk), shard)
+        if key not in self._pks:
+            if pk.curve != self.curve:
+                raise ValueError("proving key is for another curve")
+            self._pks[key] = _DevicePk(self._ctx, pk, num_inputs, shard)
+        return self._pks[key]
+
+    def _ck(self, m: ConstraintMatrices) -> _DeviceCircuit:
+        if id(m) not in self._cks:
+            self._cks[id(m)] = _DeviceCircuit(self._ctx, m)
+        return self._cks[id(m)]
+
+    def close(self):
+        for p in self._pks.values():
+            p.close()
+        for c in self._cks.values():
+            c.close()
+        self._pks, self._cks = {}, {}
+        self._ctx.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- prover.rs:26-51 -------------------------------------------------------------------
+    def create_proof_with_reduction_and_matrices(self, pk: ProvingKey, r: np.ndarray, s: np.ndarray, matrices: ConstraintMatrices,
+                                                 num_inputs: int, num_constraints: int, full_assignment: np.ndarray) -> Proof:
+        assert num_inputs == matrices.num_instance_variables and num_constraints == matrices.num_constraints
+        L = FQ_LIMBS[self.curve]
+        dpk, dck = self._pk(pk, num_inputs), self._ck(matrices)
+        z = _c(full_assignment)
+        out = ProofC()
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_prove(self._ctx.handle, dpk.handle, dck.handle, z.ctypes.data, z.shape[0], 0, ptr64(_c(r)), ptr64(_c(s)),
+                                C.byref(out)))
+        return Proof(np.array(out.a[: 2 * L], dtype=np.uint64), np.array(out.b[: 4 * L], dtype=np.uint64),
+                     np.array(out.c[: 2 * L], dtype=np.uint64))
+
+    # -- prover.rs:155-168 -----------------------------------------------------------------
+    def create_proof_with_reduction_no_zk(self, pk, matrices, num_inputs, num_constraints, full_assignment) -> Proof:
+        zero = np.zeros(4, dtype=np.uint64)
+        return self.create_proof_with_reduction_and_matrices(pk, zero, zero, matrices, num_inputs, num_constraints, full_assignment)
+
+    # -- prover.rs:138-150 -----------------------------------------------------------------
+    def create_random_proof_with_reduction(self, pk, matrices, num_inputs, num_constraints, full_assignment, rng=None) -> Proof:
+        p = _MODULUS_R[self.curve]
+
+        def rand():
+            v = (rng.getrandbits(512) if rng is not None else secrets.randbits(512)) % p
+            v = (v << 256) % p  # to Montgomery form
+            return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        return self.create_proof_with_reduction_and_matrices(pk, rand(), rand(), matrices, num_inputs, num_constraints, full_assignment)
+
+    # -- r1cs_to_qap.rs:172-235 --------------------------------------------------------------
+    def witness_map_from_matrices(self, matrices: ConstraintMatrices, num_inputs: int, num_constraints: int,
+                                  full_assignment: np.ndarray) -> np.ndarray:
+        dck = self._ck(matrices)
+        z = _c(full_assignment)
+        h = np.zeros((dck.domain_size, 4), dtype=np.uint64)
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_witness_map(self._ctx.handle, dck.handle, z.ctypes.data, z.shape[0], 0, ptr64(h)))
+        return h
+
+    # -- VariableBaseMSM::msm (scalars in Montgomery form; into_bigint happens on the GPU) ----
+    def msm(self, bases: np.ndarray, scalars: np.ndarray, g2: bool = False) -> np.ndarray:
+        L = FQ_LIMBS[self.curve]
+        n = min(len(bases), len(scalars))  # msm_bigint truncates to the shorter input
+        b, s = _c(bases[:n]), _c(scalars[:n])
+        out = np.zeros((4 if g2 else 2) * L, dtype=np.uint64)
+        lb = self._ctx.lib
+        fn = lb.c.g16_msm_g2 if g2 else lb.c.g16_msm_g1
+        lb.check(fn(self._ctx.handle, ptr64(b) if n else None, ptr64(s) if n else None, n, ptr64(out)))
+        return out
+
+    # -- EvaluationDomain::{fft, ifft, coset variants}, natural order ---------------------------
+    def ntt(self, data: np.ndarray, inverse: bool = False, coset: bool = False) -> np.ndarray:
+        d = _c(data).copy()
+        n = d.shape[0]
+        log_n = n.bit_length() - 1
+        if 1 << log_n != n:
+            raise ValueError("length must be a power of two")
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_ntt(self._ctx.handle, ptr64(d), log_n, int(inverse), int(coset)))
+        return d
+
+    def timings(self) -> dict:
+        t = TimingsC()
+        self._ctx.lib.check(self._ctx.lib.c.g16_get_timings(self._ctx.handle, C.byref(t)))
+        return t.as_dict()
+
+    # -- sharded form --------------------------------------------------------------------------
+    def prove_partial(self, pk: ProvingKey, matrices: ConstraintMatrices, full_assignment: np.ndarray, shard: Tuple[int, int],
+                      skip_b_g1: bool = False) -> bytes:
+        dpk, dck = self._pk(pk, matrices.num_instance_variables, shard), self._ck(matrices)
+        z = _c(full_assignment)
+        part = PartialC()
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_prove_partial(self._ctx.handle, dpk.handle, dck.handle, z.ctypes.data, z.shape[0], 0, int(skip_b_g1),
+                                        C.byref(part)))
+        return bytes(part)
+
+    def prove_finalize(self, pk: ProvingKey, num_inputs: int, parts: Sequence[bytes], r: np.ndarray, s: np.ndarray,
+                       shard: Tuple[int, int] = (0, 1)) -> Proof:
+        L = FQ_LIMBS[self.curve]
+        dpk = self._pk(pk, num_inputs, shard)
+        arr = (PartialC * len(parts))(*[PartialC.from_buffer_copy(p) for p in parts])
+        out = ProofC()
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_prove_finalize(self._ctx.handle, dpk.handle, arr, len(parts), ptr64(_c(r)), ptr64(_c(s)), C.byref(out)))
+        return Proof(np.array(out.a[: 2 * L], dtype=np.uint64), np.array(out.b[: 4 * L], dtype=np.uint64),
+                     np.array(out.c[: 2 * L], dtype=np.uint64))
+
+
+class ShardedProver:
+    """One process per GPU: every rank holds a contiguous shard of each MSM base array, computes its
+    partial sums, and the fixed-size records are exchanged with ONE all-gather (RCCL over xGMI when
+    the process group backend is "nccl"; gloo in the CPU tests).  Group addition is not an
+    element-wise sum, so the collective is an all-gather of ~1.2 KB per rank followed by a local
+    N-way EC addition inside g16_prove_finalize -- not an all-reduce.  The witness map is
+    replicated (it is ~5 % of a single-GPU proof)."""
+
+    PARTIAL_BYTES = C.sizeof(PartialC)
+
+    def __init__(self, prover: Groth16, pk: ProvingKey, matrices: ConstraintMatrices, rank: int, world_size: int):
+        self.prover, self.pk, self.matrices = prover, pk, matrices
+        self.rank, self.world = rank, world_size
+
+    def local_partial(self, full_assignment: np.ndarray, r: np.ndarray) -> bytes:
+        return self.prover.prove_partial(self.pk, self.matrices, full_assignment, (self.rank, self.world),
+                                         skip_b_g1=not np.asarray(r).any())
+
+    @staticmethod
+    def exchange(local: bytes, dist, device=None) -> List[bytes]:
+        """all-gather of the partial records through torch.distributed"""
+        import torch
+
+        t = torch.frombuffer(bytearray(local), dtype=torch.uint8)
+        if device is not None:
+            t = t.to(device)
+        outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, t)
+        return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+
+    def prove(self, full_assignment: np.ndarray, r: np.ndarray, s: np.ndarray, dist=None, device=None) -> Proof:
+        local = self.local_partial(full_assignment, r)
+        parts = [local] if (dist is None or self.world == 1) else self.exchange(local, dist, device)
+        return self.prover.prove_finalize(self.pk, self.matrices.num_instance_variables, parts, r, s, (self.rank, self.world))

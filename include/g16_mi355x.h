@@ -1,0 +1,185 @@
+/* g16_mi355x.h -- C ABI of the MI355X-native Groth16 prover hot path.
+ *
+ * Drop-in boundary for ark-groth16 0.5.0 (paths relative to /root/reference):
+ *   g16_prove            <->  Groth16::create_proof_with_reduction_and_matrices   src/prover.rs:26-51
+ *                             (= witness_map_from_matrices  src/r1cs_to_qap.rs:172-235
+ *                              + create_proof_with_assignment src/prover.rs:54-132)
+ *   g16_witness_map      <->  LibsnarkReduction::witness_map_from_matrices        src/r1cs_to_qap.rs:172-235
+ *   g16_msm_g1 / _g2     <->  VariableBaseMSM::msm_bigint call sites              src/prover.rs:66,74,262
+ *   g16_ntt              <->  EvaluationDomain::{fft,ifft}_in_place (+coset)      src/r1cs_to_qap.rs:201-232
+ *   g16_pk_load          <->  &ProvingKey<E>                                      src/data_structures.rs:125-143
+ *   g16_circuit_load     <->  &ConstraintMatrices<F>, num_inputs, num_constraints src/prover.rs:30-32
+ *   g16_prove_partial / g16_prove_finalize: the same proof with the MSM base set sharded
+ *                             over several GPUs (one process per GPU; the host exchanges the
+ *                             fixed-size g16_partial records, e.g. one RCCL all-gather).
+ * The reference has no FFI of its own (#![forbid(unsafe_code)], src/lib.rs:13); INTEGRATION.md
+ * shows the Rust binding a maintainer would add.
+ *
+ * Data conventions (zero conversion on the Rust side):
+ *   field element  : arkworks in-memory form -- little-endian u64 limbs of a*R mod p (Montgomery),
+ *                    Fr: 4 limbs (both curves); Fq: 6 limbs (BLS12-381) / 4 limbs (BN254)
+ *   G1 affine      : x | y              (2*FQ limbs)
+ *   G2 affine      : x.c0 x.c1 y.c0 y.c1 (4*FQ limbs)
+ *   identity       : all limbs zero (arkworks Affine::identity() has x = y = 0, infinity = true;
+ *                    (0,0) is not on either curve, so the flag is redundant)
+ *   CSR matrix     : row_ptr u64[num_constraints+1], col u32[nnz], val Fr[nnz]; built from
+ *                    ConstraintMatrices' Vec<Vec<(F, usize)>> rows
+ * All functions return 0 on success or a g16_status; they never throw or unwind.
+ * A g16_ctx is bound to one HIP device and is thread-compatible (one call in flight per ctx).
+ */
+#ifndef G16_MI355X_H
+#define G16_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    G16_OK = 0,
+    G16_ERR_DEGREE_TOO_LARGE = 1, /* SynthesisError::PolynomialDegreeTooLarge (r1cs_to_qap.rs:178-179) */
+    G16_ERR_BAD_LENGTH = 2,       /* the reference would panic on a slice bound (prover.rs:44-45)      */
+    G16_ERR_BAD_ARG = 3,
+    G16_ERR_HIP = 4,
+    G16_ERR_OOM = 5,
+    G16_ERR_NO_DEVICE = 6,
+    G16_ERR_INTERNAL = 7
+} g16_status;
+
+typedef enum { G16_BLS12_381 = 0, G16_BN254 = 1 } g16_curve;
+
+typedef struct g16_ctx g16_ctx;
+typedef struct g16_pk g16_pk;
+typedef struct g16_circuit g16_circuit;
+
+/* one query vector (or a contiguous shard of it) */
+typedef struct {
+    const uint64_t* points; /* affine points, host memory (or device memory if G16_PK_DEVICE_PTRS) */
+    uint64_t count;         /* points in this shard                                               */
+    uint64_t start;         /* index of points[0] within the logical MSM base array               */
+} g16_query;
+
+#define G16_PK_DEVICE_PTRS 1u /* query `points` are device pointers on the ctx's GPU (copied D2D) */
+
+/* ProvingKey<E> as the prover reads it (src/data_structures.rs:125-143; vk fields prover.rs:92,105,113).
+ * MSM base arrays, in the index space the prover uses:
+ *   a, b_g1, b_g2 : query[1..]   (index i <-> full_assignment[1+i]),  logical length m
+ *   l             : l_query      (index j <-> full_assignment[num_inputs+j]), logical length w
+ *   h             : h_query      (index k <-> h[k]), logical length n-1
+ * query[0] of a / b_g1 / b_g2 is passed separately (calculate_coeff, prover.rs:261). */
+typedef struct {
+    const uint64_t* alpha_g1; /* vk.alpha_g1 */
+    const uint64_t* beta_g1;
+    const uint64_t* delta_g1;
+    const uint64_t* beta_g2;  /* vk.beta_g2  */
+    const uint64_t* delta_g2; /* vk.delta_g2 */
+    const uint64_t* a_query0;
+    const uint64_t* b_g1_query0;
+    const uint64_t* b_g2_query0;
+    g16_query a, b_g1, b_g2, h, l;
+    uint32_t flags;
+} g16_pk_view;
+
+typedef struct {
+    const uint64_t* row_ptr;
+    const uint32_t* col;
+    const uint64_t* val;
+} g16_csr_view;
+
+/* Proof<E> (src/data_structures.rs:8-16), affine Montgomery limbs; only the first
+ * 2*FQ / 4*FQ / 2*FQ limbs of a / b / c are meaningful. */
+typedef struct {
+    uint64_t a[12];
+    uint64_t b[24];
+    uint64_t c[12];
+} g16_proof;
+
+/* Partial MSM sums of one shard, extended-Jacobian (X, Y, ZZ, ZZZ) Montgomery limbs.
+ * Fixed size so that it can be all-gathered as raw bytes. */
+typedef struct {
+    uint64_t h[24], l[24], a[24], b_g1[24]; /* 4*FQ limbs used */
+    uint64_t b_g2[48];                      /* 8*FQ limbs used */
+} g16_partial;
+
+/* phase timings of the last g16_prove on this ctx, milliseconds (GPU events + host clock);
+ * names follow the reference's timers (prover.rs:36,62,89,99,111,119) */
+typedef struct {
+    double witness_map_ms;
+    double msm_h_ms, msm_l_ms, msm_a_ms, msm_b_g1_ms, msm_b_g2_ms;
+    double scalar_prep_ms; /* into_bigint + digit extraction + bucket sort (shared by the MSMs) */
+    double finish_ms;      /* host glue: scalar muls, final adds, into_affine */
+    double total_ms;
+    double bucket_pass_ms; /* sum over the 5 MSMs of the bucket-accumulation kernel */
+} g16_timings;
+
+int g16_ctx_create(int curve, int device_id, g16_ctx** out);
+void g16_ctx_destroy(g16_ctx* ctx);
+/* HIP stream the ctx launches on (hipStream_t); lets callers bracket work with their own events */
+void* g16_ctx_stream(g16_ctx* ctx);
+
+int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out);
+void g16_pk_free(g16_pk* pk);
+
+/* num_variables = num_instance_variables + num_witness_variables (len of full_assignment) */
+int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints,
+                     uint64_t num_variables, g16_circuit** out);
+void g16_circuit_free(g16_circuit* c);
+uint64_t g16_circuit_domain_size(const g16_circuit* c);
+
+/* full_assignment: n_assign Fr (host memory unless assignment_on_device != 0); r, s: one Fr each */
+int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment,
+              uint64_t n_assign, int assignment_on_device, const uint64_t r[4], const uint64_t s[4], g16_proof* out);
+
+/* sharded proof: every rank runs _partial on its pk shard, the host gathers the records, any rank
+ * (all ranks, typically) runs _finalize over all of them */
+int g16_prove_partial(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment,
+                      uint64_t n_assign, int assignment_on_device, int skip_b_g1, g16_partial* out);
+int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts, int n_parts, const uint64_t r[4],
+                       const uint64_t s[4], g16_proof* out);
+
+int g16_get_timings(g16_ctx* ctx, g16_timings* out);
+
+/* ---- unit-level entry points (parity tests, micro-benchmarks) ---- */
+
+/* h_out: domain_size Fr, natural order */
+int g16_witness_map(g16_ctx* ctx, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
+                    int on_device, uint64_t* h_out);
+/* bases affine, scalars Fr in Montgomery form (into_bigint is applied on the GPU, prover.rs:63-65);
+ * out: affine result */
+int g16_msm_g1(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine);
+int g16_msm_g2(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine);
+/* in place, natural order in and out, n = 2^log_n Fr in host memory */
+int g16_ntt(g16_ctx* ctx, uint64_t* data, int log_n, int inverse, int coset);
+
+/* ---- synthetic workload generators (bench.py) ---- */
+
+/* n distinct non-identity points P_i = (s0 + first + i) * G written to DEVICE memory `out_dev`
+ * (g2 = 0: G1 affine, 1: G2 affine) */
+int g16_synth_bases(g16_ctx* ctx, int g2, uint64_t seed, uint64_t first, uint64_t n, uint64_t* out_dev);
+/* SYN(k, seed) Fibonacci-product-chain R1CS: n_c = 2^k - 2, 2 instance variables, 2^k + 1 variables.
+ * Host buffers: z_out (2^k+1) Fr, row_ptr n_c+1, colA/B/C n_c each, val n_c Fr (all one, shared). */
+int g16_synth_circuit(int curve, int k, uint64_t seed, uint64_t* z_out, uint64_t* row_ptr, uint32_t* colA,
+                      uint32_t* colB, uint32_t* colC, uint64_t* val);
+
+/* ---- host-side arithmetic self-test hooks (CPU; used by the `not gpu` tests) ----
+ * The same field / group code the kernels use, compiled for the host.
+ * which: 0 Fr, 1 Fq.  op: 0 add, 1 sub, 2 mul, 3 inverse(a), 4 to_canonical(a), 5 from_canonical(a) */
+int g16_host_field_op(int curve, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out);
+/* g2: 0/1.  op: 0 p+q (affine in, affine out), 1 k*p (k canonical 4 limbs), 2 p+q via XYZZ+XYZZ add */
+int g16_host_group_op(int curve, int g2, int op, const uint64_t* p, const uint64_t* q_or_k, uint64_t* out);
+/* CPU model of the MSM bucket method exactly as the kernels run it (signed digits, window c):
+ * checks digit extraction + bucket reduction + window fold logic without a GPU */
+int g16_host_msm_model(int curve, int g2, const uint64_t* bases, const uint64_t* scalars, uint64_t n, int c,
+                       uint64_t* out_affine);
+
+const char* g16_strerror(int status);
+/* text of the last HIP error seen on this thread ("" if none) */
+const char* g16_last_error(void);
+const char* g16_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G16_MI355X_H */
