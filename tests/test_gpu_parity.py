@@ -1,0 +1,210 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): every call goes through the C ABI of
+libg16_mi355x.so via the groth16_amd host mirror and is compared bit-for-bit with the CPU oracle on
+the same seeded inputs, plus size-independent properties at larger sizes."""
+import numpy as np
+import pytest
+
+import pymodel as pm
+from helpers import (arr_to_g1, arr_to_g2, circuit_from_pymodel, ints_to_mont, mont_to_ints, oracle, pk_from_pymodel)
+
+pytestmark = pytest.mark.gpu
+
+CURVES = ["bls12_381", "bn254"]
+CP = {"bls12_381": pm.BLS12_381, "bn254": pm.BN254}
+
+
+def mats_of(g, ck):
+    return g.ConstraintMatrices(ck.num_inputs, ck.num_vars - ck.num_inputs, ck.num_constraints, *[(m.row_ptr, m.col, m.val) for m in ck.abc])
+
+
+def pk_of(g, pk):
+    return g.ProvingKey(pk.curve, pk.alpha_g1, pk.beta_g1, pk.delta_g1, pk.beta_g2, pk.delta_g2, pk.a_query, pk.b_g1_query, pk.b_g2_query,
+                        pk.h_query, pk.l_query)
+
+
+@pytest.fixture(scope="module")
+def g():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    import groth16_amd
+
+    return groth16_amd
+
+
+@pytest.fixture(scope="module", params=CURVES)
+def env(request, g, orc):
+    prover = g.Groth16(request.param, 0)
+    yield request.param, prover
+    prover.close()
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 7, 11, 12, 13, 16, 18])
+def test_ntt_matches_oracle(env, orc, log_n):
+    curve, prover = env
+    x = orc.rand_fr(curve, 100 + log_n, 1 << log_n)
+    for inverse in (False, True):
+        for coset in (False, True):
+            got = prover.ntt(x, inverse, coset)
+            assert (got == orc.ntt(curve, x, inverse, coset)).all(), (inverse, coset)
+
+
+def test_ntt_roundtrip_2_22(env, orc):
+    """size-independent property at BASELINE.json's full domain size: ifft(fft(x)) == x, coset too"""
+    curve, prover = env
+    n = 1 << 22
+    x = np.tile(orc.rand_fr(curve, 5, 1 << 12), (n >> 12, 1))
+    x[:, 0] ^= np.arange(n, dtype=np.uint64) & np.uint64(0xFFFF)  # distinct, still < modulus (low limb tweak)
+    y = prover.ntt(x, False, True)
+    assert not (y == x).all()
+    assert (prover.ntt(y, True, True) == x).all()
+
+
+@pytest.mark.parametrize("k", [2, 3, 5, 9, 11, 13, 16])
+def test_witness_map_matches_oracle(env, orc, g, k):
+    curve, prover = env
+    ck = orc.syn_circuit(curve, k, 40 + k)
+    h = prover.witness_map_from_matrices(mats_of(g, ck), ck.num_inputs, ck.num_constraints, ck.z)
+    assert (h == orc.witness_map(ck)).all()
+    assert not h[-1].any()  # deg h <= n-2 for a satisfied system
+
+
+def test_witness_map_padded_domain_and_dense_rows(env, orc, g):
+    """nc + num_inputs not a power of two (zero padding rows) and rows with several terms"""
+    curve, prover = env
+    cp = CP[curve]
+    for cs, z in (pm.mimc_circuit(cp, 20, 4), pm.syn_circuit(cp, 5, 6, dense=True)):
+        ck = circuit_from_pymodel(cp, cs, z)
+        h = prover.witness_map_from_matrices(mats_of(g, ck), ck.num_inputs, ck.num_constraints, ck.z)
+        assert mont_to_ints(h, cp.r) == pm.witness_map_from_matrices(cp, cs, z)
+
+
+@pytest.mark.parametrize("g2", [False, True])
+@pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 257, 4096, 20000])
+def test_msm_matches_oracle(env, orc, g2, n):
+    curve, prover = env
+    bases = orc.synth_bases(curve, g2, 3, max(n, 1))[:n]
+    sc = orc.rand_fr(curve, 7 + n, max(n, 1))[:n]
+    got = prover.msm(bases, sc, g2)
+    want = orc.msm(curve, g2, bases, sc) if n else np.zeros_like(got)
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("g2", [False, True])
+def test_msm_adversarial_inputs(env, orc, g2):
+    """zero scalars, r-1, all-equal scalars (benches/bench.rs:52-54 shape), identity bases, repeated
+    bases, P and -P in the same bucket, all-zero, all-one"""
+    curve, prover = env
+    cp = CP[curve]
+    n = 3000
+    bases = orc.synth_bases(curve, g2, 11, n)
+    sc = orc.rand_fr(curve, 13, n)
+    sp = ints_to_mont([0, 1, cp.r - 1, 2, (cp.r - 1) // 2, (cp.r + 1) // 2], cp.r, 4)
+    sc[: len(sp)] = sp
+    bases[10:500:7] = 0  # identity bases
+    bases[21] = bases[20]
+    sc[21] = sc[20]  # same point twice in every bucket it lands in -> doubling branch
+    neg = bases[30].copy()
+    L = cp.fq_limbs64
+    conv, back = (None, None)
+    from helpers import g1_to_arr, g2_to_arr
+    if g2:
+        P = arr_to_g2(bases[30], cp)[0]
+        neg = g2_to_arr([pm.groups(cp)[1].neg(P)], cp)[0]
+    else:
+        P = arr_to_g1(bases[30], cp)[0]
+        neg = g1_to_arr([pm.groups(cp)[0].neg(P)], cp)[0]
+    bases[31] = neg
+    sc[31] = sc[30]  # P and -P with equal scalars cancel
+    for scal in (sc, np.repeat(sc[40:41], n, axis=0), np.zeros_like(sc), np.repeat(ints_to_mont([1], cp.r, 4), n, axis=0)):
+        assert (prover.msm(bases, scal, g2) == orc.msm(curve, g2, bases, scal)).all()
+
+
+def test_msm_linearity_large(env, orc):
+    """size-independent property at 2^20 points: msm(b, s1) + msm(b, s2) == msm(b, s1 + s2)"""
+    curve, prover = env
+    cp = CP[curve]
+    n = 1 << 20
+    bases = np.tile(orc.synth_bases(curve, False, 2, 1 << 12), (n >> 12, 1))
+    s1 = np.tile(orc.rand_fr(curve, 1, 1 << 12), (n >> 12, 1))
+    s2 = np.tile(orc.rand_fr(curve, 2, 1 << 12), (n >> 12, 1))
+    r1, r2 = prover.msm(bases, s1), prover.msm(bases, s2)
+    s12 = np.tile(np.stack([orc.field_op(curve, 0, 0, a, b) for a, b in zip(s1[: 1 << 12], s2[: 1 << 12])]), (n >> 12, 1))
+    r12 = prover.msm(bases, s12)
+    assert (orc.group_op(curve, False, 0, r1, r2) == r12).all()
+    # and against the oracle on the folded problem: sum over 256 repeats = 256 * msm(base block, s)
+    small = orc.msm(curve, False, bases[: 1 << 12], s1[: 1 << 12])
+    k = np.array([n >> 12, 0, 0, 0], dtype=np.uint64)
+    assert (orc.group_op(curve, False, 1, small, k) == r1).all()
+
+
+@pytest.mark.parametrize("k", [3, 6, 10])
+def test_proof_valid_crs_and_trapdoor(env, orc, g, k):
+    """the reference's own test pattern (src/test.rs:45-73: prove, then check) with a stronger
+    check: GPU proof == oracle proof == proof computed from the trapdoor"""
+    curve, prover = env
+    ck = orc.syn_circuit(curve, k, 1)
+    pk, ex = orc.setup(ck, 5)
+    gm, gp = mats_of(g, ck), pk_of(g, pk)
+    h = orc.witness_map(ck)
+    for r, s in ((orc.rand_fr(curve, 11, 1)[0], orc.rand_fr(curve, 12, 1)[0]),
+                 (np.zeros(4, dtype=np.uint64), orc.rand_fr(curve, 13, 1)[0]),  # r == 0 skips B in G1 (prover.rs:98)
+                 (orc.rand_fr(curve, 14, 1)[0], np.zeros(4, dtype=np.uint64))):
+        proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
+        want, _ = orc.prove(pk, ck, r, s)
+        assert (proof.flat() == want).all()
+        assert (orc.trapdoor_proof(ck, ex, h, r, s) == want).all()
+    nozk = prover.create_proof_with_reduction_no_zk(gp, gm, ck.num_inputs, ck.num_constraints, ck.z)
+    z4 = np.zeros(4, dtype=np.uint64)
+    assert (nozk.flat() == orc.prove(pk, ck, z4, z4)[0]).all()
+
+
+def test_proof_golden_pymodel(env, orc, g):
+    """MiMC and dense-row circuits generated by the big-int model (BASELINE config #1 shape)"""
+    curve, prover = env
+    cp = CP[curve]
+    for cs, z in (pm.mimc_circuit(cp, 6, 2), pm.syn_circuit(cp, 4, 1, dense=True)):
+        pk, td = pm.generate_parameters(cp, cs, 7)
+        r, s = pm.SplitMix64(1).field(cp.r), pm.SplitMix64(2).field(cp.r)
+        pr = pm.create_proof_with_reduction_and_matrices(cp, pk, r, s, cs, z)
+        ck, fpk = circuit_from_pymodel(cp, cs, z), pk_from_pymodel(cp, pk)
+        proof = prover.create_proof_with_reduction_and_matrices(pk_of(g, fpk), ints_to_mont([r], cp.r, 4)[0], ints_to_mont([s], cp.r, 4)[0],
+                                                                mats_of(g, ck), ck.num_inputs, ck.num_constraints, ck.z)
+        assert arr_to_g1(proof.a, cp)[0] == pr.a and arr_to_g2(proof.b, cp)[0] == pr.b and arr_to_g1(proof.c, cp)[0] == pr.c
+
+
+@pytest.mark.parametrize("k", [14, 16])
+def test_proof_synthetic_bases(env, orc, g, k):
+    curve, prover = env
+    ck = orc.syn_circuit(curve, k, 2)
+    pk = orc.synth_pk(ck, 9)
+    r, s = orc.rand_fr(curve, 21, 1)[0], orc.rand_fr(curve, 22, 1)[0]
+    proof = prover.create_proof_with_reduction_and_matrices(pk_of(g, pk), r, s, mats_of(g, ck), ck.num_inputs, ck.num_constraints, ck.z)
+    assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+
+
+def test_sharded_proof_equals_single(env, orc, g):
+    """MSM base sharding: 3 shards on one GPU, partial records combined by prove_finalize"""
+    curve, prover = env
+    ck = orc.syn_circuit(curve, 9, 3)
+    pk, _ = orc.setup(ck, 8)
+    gm, gp = mats_of(g, ck), pk_of(g, pk)
+    r, s = orc.rand_fr(curve, 31, 1)[0], orc.rand_fr(curve, 32, 1)[0]
+    parts = [prover.prove_partial(gp, gm, ck.z, (i, 3)) for i in range(3)]
+    proof = prover.prove_finalize(gp, ck.num_inputs, parts, r, s, (0, 3))
+    assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+
+
+def test_error_paths(env, orc, g):
+    curve, prover = env
+    ck = orc.syn_circuit(curve, 4, 3)
+    pk = orc.synth_pk(ck, 1)
+    r = orc.rand_fr(curve, 1, 1)[0]
+    with pytest.raises(g.G16Error) as e:  # assignment too short: the reference would panic on the slice (prover.rs:44-45)
+        prover.create_proof_with_reduction_and_matrices(pk_of(g, pk), r, r, mats_of(g, ck), ck.num_inputs, ck.num_constraints, ck.z[:-1])
+    assert e.value.status == 2
+    if curve == "bn254":  # 2-adicity 28: a 2^29 domain is PolynomialDegreeTooLarge (r1cs_to_qap.rs:178-179)
+        big = g.ConstraintMatrices(2, 1, (1 << 28) + 5, *[(np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.uint32),
+                                                           np.zeros((0, 4), dtype=np.uint64))] * 3)
+        with pytest.raises(g.PolynomialDegreeTooLarge):
+            prover.witness_map_from_matrices(big, 2, (1 << 28) + 5, ck.z[:3])
