@@ -60,17 +60,19 @@ class PartialC(C.Structure):
 class TimingsC(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_a_ms", "msm_b_g1_ms", "msm_b_g2_ms", "scalar_prep_ms", "finish_ms",
-        "total_ms", "bucket_pass_ms")]
+        "total_ms", "bucket_pass_ms")] + [("bucket_ms", C.c_double * 5)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "bucket_ms"}
+        d["bucket_ms"] = list(self.bucket_ms)
+        return d
 
 
 EXPORTS = [
     "g16_ctx_create", "g16_ctx_destroy", "g16_ctx_stream", "g16_pk_load", "g16_pk_free", "g16_circuit_load", "g16_circuit_free",
     "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_get_timings", "g16_witness_map",
     "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
-    "g16_host_msm_model", "g16_strerror", "g16_last_error", "g16_version",
+    "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version",
 ]
 
 
@@ -124,6 +126,7 @@ class Lib:
         c.g16_synth_circuit.argtypes = [C.c_int, C.c_int, C.c_uint64, u64p, u64p, u32p, u32p, u32p, u64p]
         c.g16_host_field_op.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
         c.g16_host_group_op.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
+        c.g16_host_selftest.argtypes = [C.c_int, C.c_uint64, C.c_int]
         c.g16_host_msm_model.argtypes = [C.c_int, C.c_int, u64p, u64p, C.c_uint64, C.c_int, u64p]
 
     def check(self, status: int):

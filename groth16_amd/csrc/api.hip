@@ -7,8 +7,10 @@
 // handful of additions, three into_affine) runs on the host with the same field code.
 #include "internal.hpp"
 #include "msm_common.hpp"
+#include "fp30.hpp"
 #include <chrono>
 #include <new>
+#include <type_traits>
 
 namespace g16 {
 
@@ -144,6 +146,11 @@ struct Impl {
         if ((rc = upload_query<G1A>(ctx, v->a, dev, &p->a)) || (rc = upload_query<G1A>(ctx, v->b_g1, dev, &p->b_g1)) ||
             (rc = upload_query<G2A>(ctx, v->b_g2, dev, &p->b_g2)) || (rc = upload_query<G1A>(ctx, v->h, dev, &p->h)) ||
             (rc = upload_query<G1A>(ctx, v->l, dev, &p->l))) {
+            pk_free(p);
+            return rc;
+        }
+        if ((rc = convert_bases_g1<C>(p->a, v->a.count, ctx->stream)) || (rc = convert_bases_g1<C>(p->b_g1, v->b_g1.count, ctx->stream)) ||
+            (rc = convert_bases_g1<C>(p->h, v->h.count, ctx->stream)) || (rc = convert_bases_g1<C>(p->l, v->l.count, ctx->stream))) {
             pk_free(p);
             return rc;
         }
@@ -327,7 +334,7 @@ struct Impl {
         tm.msm_a_ms = ctx->t_msm[2].ms();
         tm.msm_b_g1_ms = ctx->t_msm[3].ms();
         tm.msm_b_g2_ms = ctx->t_msm[4].ms();
-        for (int i = 0; i < 5; ++i) tm.bucket_pass_ms += ctx->t_bucket[i].ms();
+        for (int i = 0; i < 5; ++i) { tm.bucket_ms[i] = ctx->t_bucket[i].ms(); tm.bucket_pass_ms += tm.bucket_ms[i]; }
         tm.finish_ms = t_end - t_fold;
         tm.total_ms = t_end - t_begin;
         return G16_OK;
@@ -421,6 +428,7 @@ struct Impl {
             G16_HIP_TRY(hipMemcpyAsync(d_b, bases, n * sizeof(A), hipMemcpyHostToDevice, st));
             G16_HIP_TRY(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
         }
+        if constexpr (std::is_same<F, Fq>::value) G16_TRY((convert_bases_g1<C>(d_b, n, st)));
         ScalarSort ss;
         G16_TRY((sort_scalars<C>(d_s, n, ctx->arena, st, &ss)));
         X* ws = nullptr;
@@ -431,6 +439,7 @@ struct Impl {
         const A res = fold_windows<F>(hws.data(), ss.plan).to_affine();
         memcpy(out_affine, &res, sizeof(A));
         ctx->tm.bucket_pass_ms = ctx->t_bucket[0].ms();
+        ctx->tm.bucket_ms[0] = ctx->tm.bucket_pass_ms;
         return G16_OK;
     }
 
@@ -578,6 +587,80 @@ struct Impl {
         const A res = fold_windows<F>(wsum.data(), plan).to_affine();
         memcpy(out, &res, sizeof(A));
         return G16_OK;
+    }
+    // ---------------------------------------------------------------------------------------
+    // randomized CPU self-test of the 30-bit lazy arithmetic (fp30.hpp) against the standard field
+    // and group code; returns 0 or the number of the first failing check
+    static uint64_t sm_next(uint64_t& s) {
+        s += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+    static Fq rand_fq(uint64_t& st) {
+        Fq acc = Fq::zero();
+        const Fq two64 = Fq::from_u64(1ULL << 32).sqr();
+        for (int k = 0; k < 8; ++k) acc = acc * two64 + Fq::from_u64(sm_next(st));
+        return acc;
+    }
+    typedef Fp30<typename Fq::Params> F30;
+    static F30 to30(const Fq& x) { const Fq t = F30::std_to_r30(x); return F30::unpack(t.v); }
+    static int selftest30(uint64_t seed, int iters) {
+        uint64_t st = seed;
+        for (int it = 0; it < iters; ++it) {
+            Fq x = rand_fq(st), y = rand_fq(st);
+            if (it == 0) { x = Fq::zero(); }
+            if (it == 1) { x = Fq::zero() - Fq::one(); y = x; }
+            if (it == 2) { x = Fq::one(); }
+            const F30 a = to30(x), b = to30(y);
+            {   // pack/unpack round trip
+                Fq t = F30::std_to_r30(x), u;
+                F30::unpack(t.v).pack(u.v);
+                if (!(t == u)) return 1;
+            }
+            if (!(a.mul(b).to_std() == x * y)) return 2;
+            if (!(a.add(b).to_std() == x + y)) return 3;
+            if (!(a.template sub<2>(b).to_std() == x - y)) return 4;
+            if (!(a.template sub<8>(b).to_std() == x - y)) return 5;
+            if (!(a.neg2().to_std() == x.neg())) return 6;
+            // lazy chains: products of loosely reduced operands (< 16p)
+            const F30 big1 = a.add(b).add(a).template sub<8>(b);        // 2a, bound < 12p
+            const F30 big2 = b.template sub<8>(a).add(b);               // 2b - a, bound < 11p
+            if (!(big1.mul(big2).to_std() == (x + x) * (y + y - x))) return 7;
+            if (!(big1.sqr().to_std() == (x + x).sqr())) return 8;
+            // zero tests
+            const F30 z0 = a.template sub<8>(a);                          // == 8p
+            if (!z0.maybe_zero() || !z0.is_zero_exact()) return 9;
+            const F30 nz = a.template sub<8>(a).add(F30::one());
+            if (nz.is_zero_exact()) return 10;
+            if (a.is_zero_exact() != x.is_zero()) return 11;
+        }
+        // accumulator against the generic XYZZ code, including doubling and cancellation
+        const G1A gen = C::g1_generator();
+        std::vector<G1A> pts;
+        G1X run = G1X::from_affine(gen);
+        for (int i = 0; i < 24; ++i) {
+            uint32_t k[2] = {(uint32_t)sm_next(st) | 1u, 0};
+            pts.push_back(run.mul_bits(k, 32).to_affine());
+            run.add_affine(gen);
+        }
+        for (int round = 0; round < 4; ++round) {
+            std::vector<G1A> seq;
+            for (int i = 0; i < 40; ++i) seq.push_back(pts[sm_next(st) % pts.size()]);
+            if (round == 1) { seq[1] = seq[0]; }                          // P + P -> doubling branch
+            if (round == 2) { seq[1] = seq[0].neg(); }                    // P - P -> identity, then keep adding
+            if (round == 3) { seq[3] = seq[0]; seq[2] = seq[1]; seq[5] = seq[4].neg(); }
+            Acc30<typename Fq::Params> acc = Acc30<typename Fq::Params>::identity();
+            G1X ref = G1X::identity();
+            for (size_t i = 0; i < seq.size(); ++i) {
+                acc.add_affine(to30(seq[i].x), to30(seq[i].y));
+                ref.add_affine(seq[i]);
+                const G1A got = acc.to_std().to_affine(), want = ref.to_affine();
+                if (!(got == want)) return 100 + round * 100 + (int)i;
+            }
+        }
+        return 0;
     }
 };
 
@@ -748,6 +831,12 @@ int g16_host_msm_model(int curve, int g2, const uint64_t* bases, const uint64_t*
     if (!out_affine || (n && (!bases || !scalars))) return G16_ERR_BAD_ARG;
     if (!g2) G16_DISPATCH(curve, I::template msm_model<typename I::Fq>(bases, scalars, n, c, out_affine));
     G16_DISPATCH(curve, I::template msm_model<typename I::Fq2>(bases, scalars, n, c, out_affine));
+}
+
+int g16_host_selftest(int curve, uint64_t seed, int iters) {
+    if (curve == G16_BLS12_381) return Impl<Bls12_381>::selftest30(seed, iters);
+    if (curve == G16_BN254) return Impl<Bn254>::selftest30(seed, iters);
+    return -1;
 }
 
 const char* g16_strerror(int status) {

@@ -1,0 +1,245 @@
+// Reduced-radix (30-bit limb) Montgomery arithmetic for the bucket-accumulation kernel.
+//
+// Why: measured on MI355X (profiles/r01_ubench.txt) v_mad_u64_u32 issues in ~4-5 cycles per
+// wave, and so does every carry-handling instruction (v_add_co/v_addc, v_lshl_add_u64).  With
+// saturated 32-bit limbs each limb product drags 1-2 carry instructions plus register moves,
+// and the 288 multiply-adds of a BLS12-381 Fq product end up as <20 % of its issue cycles.
+// With 30-bit limbs a column of up to 13 limb products (< 13 * 2^60) fits a 64-bit accumulator,
+// so a product is exactly NL^2 + NL^2 v_mad_u64_u32 with NO carry instruction inside the two
+// accumulation phases, and carries are resolved once per column (shift/mask).
+//
+// Representation: NL limbs of 30 bits (NL = 13 for the 381-bit BLS12-381 Fq, 9 for 254/255-bit
+// fields), Montgomery radix R' = 2^(30 NL).  R'/p >= 2^9 gives headroom for LAZY arithmetic:
+// values are kept only "loosely" reduced (bounds noted per operation, as multiples of p); a
+// product of inputs < 16p comes out < 1.5p with no final subtraction.  Exact reduction happens
+// only when a value leaves the kernel (canonical()), or in the (rare) exceptional-case tests.
+//
+// Memory format of bases handed to the kernel: canonical x*R' mod p packed into the usual
+// 32-bit words (same size as the arkworks form; converted once at g16_pk_load time).
+#pragma once
+#include "field.hpp"
+
+namespace g16 {
+
+template <class P>
+struct Fp30 {
+    static constexpr int NL = P::NL30;
+    static constexpr int NW = P::N;  // 32-bit words of the packed form
+    static constexpr uint32_t MASK = (1u << 30) - 1u;
+    uint32_t l[NL];
+
+    G16_HD static Fp30 zero() {
+        Fp30 r;
+        G16_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = 0;
+        return r;
+    }
+    G16_HD static Fp30 one() {
+        Fp30 r;
+        G16_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = P::one30(i);
+        return r;
+    }
+    // packed little-endian words -> limbs (value unchanged)
+    G16_HD static Fp30 unpack(const uint32_t* w) {
+        Fp30 r;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            const int bit = 30 * i, wd = bit >> 5, sh = bit & 31;
+            uint32_t v = w[wd] >> sh;
+            if (sh > 2 && wd + 1 < NW) v |= w[wd + 1] << (32 - sh);
+            r.l[i] = (i == NL - 1) ? v : (v & MASK);
+        }
+        return r;
+    }
+    // limbs (normalised, value < 2^(32 NW)) -> packed words
+    G16_HD void pack(uint32_t* w) const {
+        G16_UNROLL for (int k = 0; k < NW; ++k) w[k] = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            const int bit = 30 * i, wd = bit >> 5, sh = bit & 31;
+            w[wd] |= l[i] << sh;
+            if (sh > 2 && wd + 1 < NW) w[wd + 1] |= l[i] >> (32 - sh);
+        }
+    }
+    // carry-propagate so that every limb but the top is < 2^30 (limbs may be up to 2^32 - 1 before)
+    G16_HD void normalize() {
+        G16_UNROLL for (int i = 0; i + 1 < NL; ++i) {
+            l[i + 1] += l[i] >> 30;
+            l[i] &= MASK;
+        }
+    }
+    // a + b          bound: A + B
+    G16_HD Fp30 add(const Fp30& b) const {
+        Fp30 r;
+        G16_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = l[i] + b.l[i];
+        r.normalize();
+        return r;
+    }
+    G16_HD Fp30 dbl() const { return add(*this); }
+    // a + K p - b    requires b < K p (roughly: b's top limb <= top(K p) - 1); bound: A + K
+    template <int K>
+    G16_HD Fp30 sub(const Fp30& b) const {
+        Fp30 r;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            const uint32_t kp = K == 2 ? P::kp2(i) : K == 4 ? P::kp4(i) : K == 8 ? P::kp8(i) : P::kp16(i);
+            r.l[i] = l[i] + kp - b.l[i];
+        }
+        r.normalize();
+        return r;
+    }
+    // 2p - a, for a <= 2p (used on canonical inputs)
+    G16_HD Fp30 neg2() const { return zero().template sub<2>(*this); }
+
+    // Montgomery product a*b/R' (mod p).  Inputs: normalised limbs, a < A p, b < B p with
+    // A*B*p/R' <= 0.5  (A = B = 16 is fine for every supported field); output < 1.5 p, normalised.
+    G16_HD Fp30 mul(const Fp30& b) const {
+#ifdef G16_FP30_OUTLINE
+        return mul_outlined(*this, b);
+#else
+        return mul_impl(b);
+#endif
+    }
+    G16_HD Fp30 mul_impl(const Fp30& b) const {
+        uint64_t T[2 * NL];
+        G16_UNROLL for (int c = 0; c < 2 * NL; ++c) T[c] = 0;
+        // phase 1: schoolbook columns, <= NL products of < 2^60 each: no overflow, no carries
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)l[i] * b.l[j];
+        }
+        // phase 2: one carry sweep -> every column < 2^30 (top column takes the rest)
+        G16_UNROLL for (int c = 0; c + 1 < 2 * NL; ++c) {
+            T[c + 1] += T[c] >> 30;
+            T[c] &= MASK;
+        }
+        // phase 3: Montgomery reduction, one limb at a time; each column again receives <= NL products
+        uint64_t carry = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            T[i] += carry;
+            const uint32_t m = ((uint32_t)T[i] * P::PINV30) & MASK;
+            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)m * P::p30(j);
+            carry = T[i] >> 30;  // low 30 bits are zero now
+        }
+        // phase 4: upper half + carries -> result limbs
+        Fp30 r;
+        G16_UNROLL for (int j = 0; j < NL; ++j) {
+            const uint64_t v = T[NL + j] + carry;
+            r.l[j] = (j == NL - 1) ? (uint32_t)v : ((uint32_t)v & MASK);
+            carry = v >> 30;
+        }
+        return r;
+    }
+    G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
+    G16_HD Fp30 sqr() const { return mul(*this); }
+
+    // exact: is the value (any bound < 16p, normalised) congruent to 0 mod p?
+    // Fast filter on the low limb: v = k p with k < 16 forces (v0 * p^-1 mod 2^30) = k < 16.
+    G16_HD bool maybe_zero() const { return ((l[0] * P::PPINV30) & MASK) < 16u; }
+    G16_HD bool is_zero_exact() const {
+        const uint32_t k = (l[0] * P::PPINV30) & MASK;
+        if (k >= 16u) return false;
+        Fp30 kp;
+        uint64_t c = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            const uint64_t v = (uint64_t)k * P::p30(i) + c;
+            kp.l[i] = (i == NL - 1) ? (uint32_t)v : ((uint32_t)v & MASK);
+            c = v >> 30;
+        }
+        uint32_t diff = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) diff |= kp.l[i] ^ l[i];
+        return diff == 0;
+    }
+    // exact reduction to [0, p) of a normalised value < 2p (e.g. a product output)
+    G16_HD Fp30 canonical_lt2p() const {
+        Fp30 d;
+        int32_t br = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            const int32_t v = (int32_t)l[i] - (int32_t)P::p30(i) + br;  // |v| < 2^31
+            if (i == NL - 1) { d.l[i] = (uint32_t)v; br = v >> 31; }
+            else { d.l[i] = (uint32_t)v & MASK; br = v >> 30; }
+        }
+        // br < 0  <=>  value < p
+        Fp30 r;
+        const bool lt = br < 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = lt ? l[i] : d.l[i];
+        return r;
+    }
+
+    // conversions to / from the standard arkworks Montgomery form (x*R mod p, 32-bit words)
+    // std -> packed R' form: one standard product by the plain integer R' mod p
+    G16_HD static Fp<P> std_to_r30(const Fp<P>& x) {
+        Fp<P> c;
+        G16_UNROLL for (int i = 0; i < P::N; ++i) c.v[i] = P::r30_plain(i);
+        return x * c;  // x R * (R' mod p) / R = x R' mod p, canonical
+    }
+    // lazy internal value (< 16p) -> standard form, canonical: one 30-bit product by (R mod p)
+    G16_HD Fp<P> to_std() const {
+        Fp30 c;
+        G16_UNROLL for (int i = 0; i < NL; ++i) c.l[i] = P::rstd30(i);
+        const Fp30 t = mul(c).canonical_lt2p();  // x R' * R / R' = x R mod p
+        Fp<P> r;
+        t.pack(r.v);
+        return r;
+    }
+};
+
+// Lazy extended-Jacobian accumulator over Fp30 (G1).  Invariants between calls:
+//   x < 7.5p, y < 3.5p, zz < 1.5p, zzz < 1.5p  (limbs normalised); identity kept as a flag.
+template <class P>
+struct Acc30 {
+    typedef Fp30<P> F;
+    F x, y, zz, zzz;
+    bool inf;
+
+    G16_HD static Acc30 identity() {
+        Acc30 a;
+        a.x = a.y = a.zz = a.zzz = F::zero();
+        a.inf = true;
+        return a;
+    }
+    // mdbl-2008-s-1 on an affine point (px, py canonical or < 2p)
+    G16_HD void set_double(const F& px, const F& py) {
+        const F U = py.dbl();                     // < 4p
+        if (U.is_zero_exact()) { inf = true; return; }
+        const F V = U.sqr();                      // < 1.5p
+        const F W = U.mul(V);
+        const F S = px.mul(V);
+        const F X2 = px.sqr();
+        const F M = X2.dbl().add(X2);             // < 4.5p
+        const F X3 = M.sqr().template sub<4>(S.dbl());          // < 5.5p
+        const F Y3 = M.mul(S.template sub<8>(X3)).template sub<2>(W.mul(py));  // < 3.5p
+        x = X3; y = Y3; zz = V; zzz = W;
+        inf = false;
+    }
+    // madd-2008-s: this += (px, py), affine, px,py < 2p, not the identity
+    G16_HD void add_affine(const F& px, const F& py) {
+        if (inf) {
+            x = px; y = py; zz = F::one(); zzz = F::one();
+            inf = false;
+            return;
+        }
+        const F U2 = px.mul(zz);                  // < 1.5p
+        const F S2 = py.mul(zzz);
+        const F Pd = U2.template sub<8>(x);       // < 9.5p
+        const F R = S2.template sub<4>(y);        // < 5.5p
+        if (Pd.maybe_zero()) {
+            if (Pd.is_zero_exact()) {
+                if (R.is_zero_exact()) set_double(px, py);
+                else inf = true;
+                return;
+            }
+        }
+        const F PP = Pd.sqr();                    // < 1.5p
+        const F PPP = Pd.mul(PP);
+        const F Q = x.mul(PP);
+        const F X3 = R.sqr().template sub<2>(PPP).template sub<4>(Q.dbl());        // < 7.5p
+        const F Y3 = R.mul(Q.template sub<8>(X3)).template sub<2>(y.mul(PPP));     // < 3.5p
+        x = X3;
+        y = Y3;
+        zz = zz.mul(PP);
+        zzz = zzz.mul(PPP);
+    }
+    // leave the kernel: standard-form XYZZ (canonical coordinates)
+    G16_HD XYZZ<Fp<P>> to_std() const {
+        if (inf) return XYZZ<Fp<P>>::identity();
+        return {x.to_std(), y.to_std(), zz.to_std(), zzz.to_std()};
+    }
+};
+
+}  // namespace g16

@@ -187,18 +187,27 @@ class Groth16:
         if key not in self._pks:
             if pk.curve != self.curve:
                 raise ValueError("proving key is for another curve")
-            self._pks[key] = _DevicePk(self._ctx, pk, num_inputs, shard)
-        return self._pks[key]
+            # the cache entry holds a reference to pk so that id(pk) cannot be recycled while it lives
+            self._pks[key] = (pk, _DevicePk(self._ctx, pk, num_inputs, shard))
+        return self._pks[key][1]
 
     def _ck(self, m: ConstraintMatrices) -> _DeviceCircuit:
         if id(m) not in self._cks:
-            self._cks[id(m)] = _DeviceCircuit(self._ctx, m)
-        return self._cks[id(m)]
+            self._cks[id(m)] = (m, _DeviceCircuit(self._ctx, m))
+        return self._cks[id(m)][1]
+
+    def evict(self):
+        """drop every cached device-resident key / circuit (frees their HBM)"""
+        for _, p in self._pks.values():
+            p.close()
+        for _, c in self._cks.values():
+            c.close()
+        self._pks, self._cks = {}, {}
 
     def close(self):
-        for p in self._pks.values():
+        for _, p in self._pks.values():
             p.close()
-        for c in self._cks.values():
+        for _, c in self._cks.values():
             c.close()
         self._pks, self._cks = {}, {}
         self._ctx.close()

@@ -112,6 +112,7 @@ typedef struct {
     double finish_ms;      /* host glue: scalar muls, final adds, into_affine */
     double total_ms;
     double bucket_pass_ms; /* sum over the 5 MSMs of the bucket-accumulation kernel */
+    double bucket_ms[5];   /* that kernel per MSM: h, l, a, b_g1 (G1 kernel), b_g2 (G2 kernel); HIP events on the ctx stream */
 } g16_timings;
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out);
@@ -173,6 +174,10 @@ int g16_host_group_op(int curve, int g2, int op, const uint64_t* p, const uint64
  * checks digit extraction + bucket reduction + window fold logic without a GPU */
 int g16_host_msm_model(int curve, int g2, const uint64_t* bases, const uint64_t* scalars, uint64_t n, int c,
                        uint64_t* out_affine);
+
+/* randomized CPU self-test of the reduced-radix (30-bit limb) arithmetic used by the bucket kernel against the
+ * standard field / group code; 0 = all checks passed, otherwise the number of the first failing check */
+int g16_host_selftest(int curve, uint64_t seed, int iters);
 
 const char* g16_strerror(int status);
 /* text of the last HIP error seen on this thread ("" if none) */

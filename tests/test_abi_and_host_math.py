@@ -114,6 +114,13 @@ def test_host_msm_model(lb, orc, cp, c_win):
 
 
 @pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
+def test_host_selftest_fp30(lb, cp):
+    """reduced-radix lazy arithmetic of the G1 bucket kernel (fp30.hpp) vs the standard field / group code"""
+    for seed in (1, 2, 3):
+        assert lb.c.g16_host_selftest(CURVE_ID[cp.name], seed, 400) == 0
+
+
+@pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
 def test_synth_circuit_matches_oracle(lb, orc, cp):
     k = 6
     nc = (1 << k) - 2

@@ -7,8 +7,8 @@ mkdir -p tools/bin
 build() { # name, flags
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$CS -I include $2 -DG16_VARIANT="\"$1\"" tools/ubench.hip $CS/synth.hip -o tools/bin/ubench_$1 &
 }
-build outlined_ref "-DG16_UBENCH_OPS"
-build outlined_val "-DG16_MUL_BYVAL"
-build inlined "-DG16_NOINLINE_MUL_LIMBS=99"
+rm -f tools/bin/ubench_*
+build fp30_inline "-DG16_UBENCH_OPS"
+build fp30_outline "-DG16_FP30_OUTLINE"
 wait
 ls -la tools/bin

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <vector>
 #include "internal.hpp"
+#include "fp30.hpp"
 using namespace g16;
 namespace g16 { void set_last_error(const char* w, hipError_t e, const char* f, int l) { printf("HIP error %s: %s (%s:%d)\n", w, hipGetErrorString(e), f, l); } }
 
@@ -120,7 +121,10 @@ static int run_acc(const char* name, int g2) {
         const uint32_t T = 256 * 4 * 64 * 4;
         CK(hipMalloc(&d_in, sizeof(Fq) * (T + 1)));
         CK(hipMalloc(&d_out, sizeof(Fq) * T));
-        CK(hipMemcpy(d_in, d_b, sizeof(Fq) * (T + 1), hipMemcpyDeviceToDevice));
+        for (uint32_t off = 0; off < T + 1; off += 65536) {
+            const uint32_t cnt = (T + 1 - off) < 65536 ? (T + 1 - off) : 65536;
+            CK(hipMemcpy(d_in + off, d_b, sizeof(Fq) * cnt, hipMemcpyDeviceToDevice));
+        }
         const int iters = 256;
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
@@ -132,6 +136,79 @@ static int run_acc(const char* name, int g2) {
         const double muls = (double)T * iters * 2;
         printf("MULPROBE %-28s variant=%s  %.3f ms for %.0f Fq muls => %.2f Gmul/s  (%.0f SIMD-cycles@2.4GHz per wave-mul)\n", name, G16_VARIANT, ms,
                muls, muls / ms / 1e6, ms * 1e-3 * 2.4e9 / (muls / 64 / 1024));
+        (void)hipFree(d_in); (void)hipFree(d_out);
+    }
+    (void)hipFree(d_b); (void)hipFree(d_o);
+    return 0;
+}
+
+template <class P>
+__global__ __launch_bounds__(128) void acc30_probe(const Affine<Fp<P>>* __restrict__ bases, uint32_t nb, uint32_t len, XYZZ<Fp<P>>* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 128 + threadIdx.x;
+    Acc30<P> acc = Acc30<P>::identity();
+    uint32_t x = t * 2654435761u + 1u;
+    for (uint32_t e = 0; e < len; ++e) {
+        x = x * 1664525u + 1013904223u;
+        const Affine<Fp<P>> p = bases[(x >> 4) % nb];
+        const Fp30<P> px = Fp30<P>::unpack(p.x.v);
+        Fp30<P> py = Fp30<P>::unpack(p.y.v);
+        if (x & 1) py = py.neg2();
+        acc.add_affine(px, py);
+    }
+    out[t] = acc.to_std();
+}
+template <class P>
+__global__ void mul30_probe(const Fp<P>* __restrict__ in, Fp<P>* __restrict__ out, int iters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp30<P> a = Fp30<P>::unpack(in[t].v), b = Fp30<P>::unpack(in[t + 1].v);
+    for (int i = 0; i < iters; ++i) { a = a.mul(b); b = b.mul(a); }
+    a.add(b).canonical_lt2p().pack(out[t].v);
+}
+
+template <class C>
+static int run_acc30(const char* name, int waves_per_simd) {
+    typedef typename C::Fq Fq;
+    typedef typename Fq::Params P;
+    const uint32_t nb = 1 << 16, len = 64;
+    const uint32_t threads = 256 * 4 * 64 * waves_per_simd;
+    Affine<Fq>* d_b; XYZZ<Fq>* d_o;
+    CK(hipMalloc(&d_b, sizeof(Affine<Fq>) * nb));
+    CK(hipMalloc(&d_o, sizeof(XYZZ<Fq>) * threads));
+    if (synth_bases_device<C>(0, 1, 0, nb, d_b, 0) != 0) { printf("synth failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((acc30_probe<P>), dim3(threads / 128), dim3(128), 0, 0, d_b, nb, len, d_o);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double adds = (double)threads * len;
+    printf("ACC30PROBE %-20s variant=%s waves/SIMD=%d  %.3f ms for %.0f mixed adds => %.2f Gadd/s\n", name, G16_VARIANT, waves_per_simd, ms, adds,
+           adds / ms / 1e6);
+    {
+        Fq *d_in, *d_out;
+        const uint32_t T = threads;
+        CK(hipMalloc(&d_in, sizeof(Fq) * (T + 1)));
+        CK(hipMalloc(&d_out, sizeof(Fq) * T));
+        for (uint32_t off = 0; off < T + 1; off += 65536) {
+            const uint32_t cnt = (T + 1 - off) < 65536 ? (T + 1 - off) : 65536;
+            CK(hipMemcpy(d_in + off, d_b, sizeof(Fq) * cnt, hipMemcpyDeviceToDevice));
+        }
+        const int iters = 256;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((mul30_probe<P>), dim3(T / 256), dim3(256), 0, 0, d_in, d_out, iters);
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+        }
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double muls = (double)T * iters * 2;
+        printf("MUL30PROBE %-20s variant=%s waves/SIMD=%d  %.3f ms for %.0f muls => %.2f Gmul/s  (%.0f SIMD-cycles@2.4GHz per wave-mul)\n", name,
+               G16_VARIANT, waves_per_simd, ms, muls, muls / ms / 1e6, ms * 1e-3 * 2.4e9 / (muls / 64 / 1024));
         (void)hipFree(d_in); (void)hipFree(d_out);
     }
     (void)hipFree(d_b); (void)hipFree(d_o);
@@ -151,8 +228,12 @@ int main(int argc, char** argv) {
         run_op<OP_ADD32>(d_out, w);
     }
 #endif
+    for (int w : {1, 2}) { run_acc30<Bls12_381>("bls12_381 G1", w); run_acc30<Bn254>("bn254 G1", w); }
+#ifdef G16_UBENCH_OPS
     run_acc<Bls12_381, Bls12_381::Fq>("bls12_381 G1", 0);
     run_acc<Bn254, Bn254::Fq>("bn254 G1", 0);
     run_acc<Bls12_381, Bls12_381::Fq2>("bls12_381 G2", 1);
+    run_acc<Bn254, Bn254::Fq2>("bn254 G2", 1);
+#endif
     return 0;
 }
