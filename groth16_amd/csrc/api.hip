@@ -149,8 +149,9 @@ struct Impl {
             pk_free(p);
             return rc;
         }
-        if ((rc = convert_bases_g1<C>(p->a, v->a.count, ctx->stream)) || (rc = convert_bases_g1<C>(p->b_g1, v->b_g1.count, ctx->stream)) ||
-            (rc = convert_bases_g1<C>(p->h, v->h.count, ctx->stream)) || (rc = convert_bases_g1<C>(p->l, v->l.count, ctx->stream))) {
+        if ((rc = convert_bases<Fq>(p->a, v->a.count, ctx->stream)) || (rc = convert_bases<Fq>(p->b_g1, v->b_g1.count, ctx->stream)) ||
+            (rc = convert_bases<Fq>(p->h, v->h.count, ctx->stream)) || (rc = convert_bases<Fq>(p->l, v->l.count, ctx->stream)) ||
+            (rc = convert_bases<Fq2>(p->b_g2, v->b_g2.count, ctx->stream))) {
             pk_free(p);
             return rc;
         }
@@ -428,7 +429,7 @@ struct Impl {
             G16_HIP_TRY(hipMemcpyAsync(d_b, bases, n * sizeof(A), hipMemcpyHostToDevice, st));
             G16_HIP_TRY(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
         }
-        if constexpr (std::is_same<F, Fq>::value) G16_TRY((convert_bases_g1<C>(d_b, n, st)));
+        G16_TRY((convert_bases<F>(d_b, n, st)));
         ScalarSort ss;
         G16_TRY((sort_scalars<C>(d_s, n, ctx->arena, st, &ss)));
         X* ws = nullptr;
@@ -651,13 +652,53 @@ struct Impl {
             if (round == 1) { seq[1] = seq[0]; }                          // P + P -> doubling branch
             if (round == 2) { seq[1] = seq[0].neg(); }                    // P - P -> identity, then keep adding
             if (round == 3) { seq[3] = seq[0]; seq[2] = seq[1]; seq[5] = seq[4].neg(); }
-            Acc30<typename Fq::Params> acc = Acc30<typename Fq::Params>::identity();
+            Acc30<F30> acc = Acc30<F30>::identity();
             G1X ref = G1X::identity();
             for (size_t i = 0; i < seq.size(); ++i) {
                 acc.add_affine(to30(seq[i].x), to30(seq[i].y));
                 ref.add_affine(seq[i]);
                 const G1A got = acc.to_std().to_affine(), want = ref.to_affine();
                 if (!(got == want)) return 100 + round * 100 + (int)i;
+            }
+        }
+        // ---- Fq2 over the 30-bit field, and the G2 accumulator
+        typedef Fp2x30<typename Fq::Params> F230;
+        for (int it = 0; it < iters / 4 + 4; ++it) {
+            Fq2 x = {rand_fq(st), rand_fq(st)}, y = {rand_fq(st), rand_fq(st)};
+            if (it == 0) x = Fq2::zero();
+            if (it == 1) { x = {Fq::zero() - Fq::one(), Fq::zero() - Fq::one()}; y = x; }
+            const F230 a = {to30(x.c0), to30(x.c1)}, b = {to30(y.c0), to30(y.c1)};
+            if (!(a.mul_impl(b).to_std() == x.mul_inlined(y))) return 20;
+            if (!(a.sqr_impl().to_std() == x.sqr_inlined())) return 21;
+            if (!(a.mul(b).to_std() == x * y)) return 22;
+            const F230 big1 = a.add(b).add(a).template sub<8>(b), big2 = b.template sub<8>(a).add(b);  // 2a (<12p), 2b - a (<11p)
+            if (!(big1.mul_impl(big2).to_std() == (x + x) * (y + y - x))) return 23;
+            if (!(big1.sqr_impl().to_std() == (x + x).sqr())) return 24;
+            if (a.is_zero_exact() != x.is_zero()) return 25;
+            if (!a.template sub<8>(a).is_zero_exact()) return 26;
+        }
+        {
+            const G2A gen2 = C::g2_generator();
+            std::vector<G2A> pts2;
+            G2X run2 = G2X::from_affine(gen2);
+            for (int i = 0; i < 12; ++i) {
+                uint32_t k[2] = {(uint32_t)sm_next(st) | 1u, 0};
+                pts2.push_back(run2.mul_bits(k, 32).to_affine());
+                run2.add_affine(gen2);
+            }
+            for (int round = 0; round < 3; ++round) {
+                std::vector<G2A> seq;
+                for (int i = 0; i < 24; ++i) seq.push_back(pts2[sm_next(st) % pts2.size()]);
+                if (round == 1) { seq[1] = seq[0]; }
+                if (round == 2) { seq[1] = seq[0].neg(); seq[4] = seq[3]; }
+                Acc30<F230> acc = Acc30<F230>::identity();
+                G2X ref = G2X::identity();
+                for (size_t i = 0; i < seq.size(); ++i) {
+                    const F230 px = {to30(seq[i].x.c0), to30(seq[i].x.c1)}, py = {to30(seq[i].y.c0), to30(seq[i].y.c1)};
+                    acc.add_affine(px, py);
+                    ref.add_affine(seq[i]);
+                    if (!(acc.to_std().to_affine() == ref.to_affine())) return 1000 + round * 100 + (int)i;
+                }
             }
         }
         return 0;

@@ -86,6 +86,10 @@ struct Fp30 {
     }
     // 2p - a, for a <= 2p (used on canonical inputs)
     G16_HD Fp30 neg2() const { return zero().template sub<2>(*this); }
+    // 16p - a, for a < 16p
+    G16_HD Fp30 neg16() const { return zero().template sub<16>(*this); }
+    typedef Fp<P> Std;
+    G16_HD static Fp30 from_packed(const Std& x) { return unpack(x.v); }
 
     // Montgomery product a*b/R' (mod p).  Inputs: normalised limbs, a < A p, b < B p with
     // A*B*p/R' <= 0.5  (A = B = 16 is fine for every supported field); output < 1.5 p, normalised.
@@ -96,27 +100,36 @@ struct Fp30 {
         return mul_impl(b);
 #endif
     }
-    G16_HD Fp30 mul_impl(const Fp30& b) const {
-        uint64_t T[2 * NL];
+    // ---- double-width column primitives (T has 2*NL 64-bit columns) -----------------------------
+    // T = a*b as NL^2 limb products; every column <= NL * 2^60: no overflow, no carries
+    G16_HD static void wide_mul(uint64_t* T, const Fp30& a, const Fp30& b) {
         G16_UNROLL for (int c = 0; c < 2 * NL; ++c) T[c] = 0;
-        // phase 1: schoolbook columns, <= NL products of < 2^60 each: no overflow, no carries
         G16_UNROLL for (int i = 0; i < NL; ++i) {
-            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)l[i] * b.l[j];
+            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)a.l[i] * b.l[j];
         }
-        // phase 2: one carry sweep -> every column < 2^30 (top column takes the rest)
+    }
+    // T += a*b; T must be normalised (columns < 2^30 + small) on entry
+    G16_HD static void wide_mul_add(uint64_t* T, const Fp30& a, const Fp30& b) {
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)a.l[i] * b.l[j];
+        }
+    }
+    // one carry sweep -> every column < 2^30 (the top column takes the rest)
+    G16_HD static void wide_normalize(uint64_t* T) {
         G16_UNROLL for (int c = 0; c + 1 < 2 * NL; ++c) {
             T[c + 1] += T[c] >> 30;
             T[c] &= MASK;
         }
-        // phase 3: Montgomery reduction, one limb at a time; each column again receives <= NL products
+    }
+    // Montgomery reduction of a normalised T (value < ~400 p^2): returns T / R' mod p, < p (1 + T/(R' p))
+    G16_HD static Fp30 wide_redc(uint64_t* T) {
         uint64_t carry = 0;
         G16_UNROLL for (int i = 0; i < NL; ++i) {
             T[i] += carry;
             const uint32_t m = ((uint32_t)T[i] * P::PINV30) & MASK;
-            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)m * P::p30(j);
+            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)m * P::p30(j);  // column again gets <= NL products
             carry = T[i] >> 30;  // low 30 bits are zero now
         }
-        // phase 4: upper half + carries -> result limbs
         Fp30 r;
         G16_UNROLL for (int j = 0; j < NL; ++j) {
             const uint64_t v = T[NL + j] + carry;
@@ -124,6 +137,12 @@ struct Fp30 {
             carry = v >> 30;
         }
         return r;
+    }
+    G16_HD Fp30 mul_impl(const Fp30& b) const {
+        uint64_t T[2 * NL];
+        wide_mul(T, *this, b);
+        wide_normalize(T);
+        return wide_redc(T);
     }
     G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
     G16_HD Fp30 sqr() const { return mul(*this); }
@@ -179,11 +198,68 @@ struct Fp30 {
     }
 };
 
-// Lazy extended-Jacobian accumulator over Fp30 (G1).  Invariants between calls:
-//   x < 7.5p, y < 3.5p, zz < 1.5p, zzz < 1.5p  (limbs normalised); identity kept as a flag.
+// Fq2 = Fq[u]/(u^2+1) over the 30-bit lazy field.  A product is 4 limb-product sweeps + 2 reductions
+// (lazy reduction: the two double-width sums are reduced once each), i.e. 6 NL^2 multiply-adds -- the
+// same count as Karatsuba's 3 full products, with outputs that obey the single-product bound (< 1.5p)
+// so the group formulas and their K constants are shared with G1.  Inputs: components < 16p.
 template <class P>
+struct Fp2x30 {
+    typedef Fp30<P> B;
+    typedef Fp2<P> Std;
+    B c0, c1;
+    G16_HD static Fp2x30 zero() { return {B::zero(), B::zero()}; }
+    G16_HD static Fp2x30 one() { return {B::one(), B::zero()}; }
+    G16_HD static Fp2x30 from_packed(const Std& x) { return {B::unpack(x.c0.v), B::unpack(x.c1.v)}; }
+    G16_HD Fp2x30 add(const Fp2x30& o) const { return {c0.add(o.c0), c1.add(o.c1)}; }
+    G16_HD Fp2x30 dbl() const { return {c0.dbl(), c1.dbl()}; }
+    template <int K>
+    G16_HD Fp2x30 sub(const Fp2x30& o) const { return {c0.template sub<K>(o.c0), c1.template sub<K>(o.c1)}; }
+    G16_HD Fp2x30 neg2() const { return {c0.neg2(), c1.neg2()}; }
+    G16_HD Fp2x30 mul_impl(const Fp2x30& o) const {
+        uint64_t T[2 * B::NL];
+        Fp2x30 r;
+        const B nb1 = o.c1.neg16();           // 16p - b1
+        B::wide_mul(T, c0, o.c0);             // a0 b0 + a1 (16p - b1)  ==  a0 b0 - a1 b1  (mod p)
+        B::wide_normalize(T);
+        B::wide_mul_add(T, c1, nb1);
+        B::wide_normalize(T);
+        r.c0 = B::wide_redc(T);
+        B::wide_mul(T, c0, o.c1);             // a0 b1 + a1 b0
+        B::wide_normalize(T);
+        B::wide_mul_add(T, c1, o.c0);
+        B::wide_normalize(T);
+        r.c1 = B::wide_redc(T);
+        return r;
+    }
+    G16_HD Fp2x30 sqr_impl() const {          // (a0 + a1)(a0 - a1), 2 a0 a1
+        return {c0.add(c1).mul_impl(c0.template sub<16>(c1)), c0.dbl().mul_impl(c1)};
+    }
+    G16_HD_NOINLINE static Fp2x30 mul_outlined(const Fp2x30& a, const Fp2x30& b) { return a.mul_impl(b); }
+    G16_HD_NOINLINE static Fp2x30 sqr_outlined(const Fp2x30& a) { return a.sqr_impl(); }
+    G16_HD Fp2x30 mul(const Fp2x30& o) const {
+#ifdef G16_FP2X30_INLINE
+        return mul_impl(o);
+#else
+        return mul_outlined(*this, o);
+#endif
+    }
+    G16_HD Fp2x30 sqr() const {
+#ifdef G16_FP2X30_INLINE
+        return sqr_impl();
+#else
+        return sqr_outlined(*this);
+#endif
+    }
+    G16_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
+    G16_HD bool is_zero_exact() const { return c0.is_zero_exact() && c1.is_zero_exact(); }
+    G16_HD Std to_std() const { return {c0.to_std(), c1.to_std()}; }
+};
+
+// Lazy extended-Jacobian accumulator, F = Fp30<P> (G1) or Fp2x30<P> (G2).  Invariants between calls
+// (per base-field component): x < 7.5p, y < 3.5p, zz < 1.8p, zzz < 1.5p; identity kept as a flag.
+template <class F>
 struct Acc30 {
-    typedef Fp30<P> F;
+    typedef typename F::Std StdF;
     F x, y, zz, zzz;
     bool inf;
 
@@ -193,7 +269,7 @@ struct Acc30 {
         a.inf = true;
         return a;
     }
-    // mdbl-2008-s-1 on an affine point (px, py canonical or < 2p)
+    // mdbl-2008-s-1 on an affine point (px, py < 2p)
     G16_HD void set_double(const F& px, const F& py) {
         const F U = py.dbl();                     // < 4p
         if (U.is_zero_exact()) { inf = true; return; }
@@ -225,8 +301,8 @@ struct Acc30 {
                 return;
             }
         }
-        const F PP = Pd.sqr();                    // < 1.5p
-        const F PPP = Pd.mul(PP);
+        const F PP = Pd.sqr();                    // < 1.8p (Fq2 squaring of a 9.5p operand)
+        const F PPP = Pd.mul(PP);                 // < 1.5p
         const F Q = x.mul(PP);
         const F X3 = R.sqr().template sub<2>(PPP).template sub<4>(Q.dbl());        // < 7.5p
         const F Y3 = R.mul(Q.template sub<8>(X3)).template sub<2>(y.mul(PPP));     // < 3.5p
@@ -236,8 +312,8 @@ struct Acc30 {
         zzz = zzz.mul(PPP);
     }
     // leave the kernel: standard-form XYZZ (canonical coordinates)
-    G16_HD XYZZ<Fp<P>> to_std() const {
-        if (inf) return XYZZ<Fp<P>>::identity();
+    G16_HD XYZZ<StdF> to_std() const {
+        if (inf) return XYZZ<StdF>::identity();
         return {x.to_std(), y.to_std(), zz.to_std(), zzz.to_std()};
     }
 };

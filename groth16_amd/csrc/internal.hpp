@@ -134,9 +134,9 @@ template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n,
 // is issued by the caller; d_window_sums is arena memory.
 template <class F> int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena,
                                       hipStream_t st, XYZZ<F>** d_window_sums, EventTimer* bucket_timer);
-// G1 bases are kept on the device in the bucket kernel's own Montgomery radix (x*R' with R' = 2^(30 NL), canonical,
-// packed in the usual words): converted in place, once, after upload.  G2 bases stay in the standard form.
-template <class C> int convert_bases_g1(Affine<typename C::Fq>* d_bases, uint64_t n, hipStream_t st);
+// MSM bases are kept on the device in the bucket kernel's own Montgomery radix (x*R' with R' = 2^(30 NL), canonical,
+// packed in the usual words): converted in place, once, after upload (F = Fq for G1, Fq2 for G2).
+template <class F> int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st);
 // host: sum_w 2^(c w) R_w
 template <class F> XYZZ<F> fold_windows(const XYZZ<F>* window_sums, const MsmPlan& plan);
 

@@ -201,15 +201,16 @@ __global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate_kernel(const Af
     partials[t] = acc;
 }
 
-// G1 variant on the 30-bit lazy arithmetic (fp30.hpp).  `bases` hold canonical x*R', y*R' packed in
-// 32-bit words (convert_bases30_kernel); partial sums leave in the standard Montgomery form so
-// the reduction kernels and the host are unaffected.
-template <class P>
-__global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate30_kernel(const Affine<Fp<P>>* __restrict__ bases, int64_t shift,
-                                                                          uint64_t base_count, const uint32_t* __restrict__ sorted,
+// Production variant on the 30-bit lazy arithmetic (fp30.hpp), F30 = Fp30<P> (G1) or Fp2x30<P> (G2).
+// `bases` hold canonical x*R', y*R' packed in 32-bit words (convert_bases30_kernel); partial sums
+// leave in the standard Montgomery form so the reduction kernels and the host are unaffected.
+template <class F30>
+__global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate30_kernel(const Affine<typename F30::Std>* __restrict__ bases,
+                                                                          int64_t shift, uint64_t base_count,
+                                                                          const uint32_t* __restrict__ sorted,
                                                                           const uint32_t* __restrict__ offsets,
                                                                           const uint32_t* __restrict__ task_off, uint32_t M,
-                                                                          uint32_t lmax_log, XYZZ<Fp<P>>* __restrict__ partials) {
+                                                                          uint32_t lmax_log, XYZZ<typename F30::Std>* __restrict__ partials) {
     const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
     const uint32_t ntasks = task_off[M];
     if (t >= ntasks) return;
@@ -221,47 +222,37 @@ __global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate30_kernel(const 
     const uint32_t k = t - task_off[lo];
     const uint32_t start = offsets[lo] + (k << lmax_log);
     const uint32_t end = min(offsets[lo + 1], start + (1u << lmax_log));
-    Acc30<P> acc = Acc30<P>::identity();
+    Acc30<F30> acc = Acc30<F30>::identity();
     for (uint32_t e = start; e < end; ++e) {
         const uint32_t v = sorted[e];
         const int64_t idx = (int64_t)(v & 0x7fffffffu) + shift;
         if (idx < 0 || (uint64_t)idx >= base_count) continue;
-        const Affine<Fp<P>> p = bases[idx];
+        const Affine<typename F30::Std> p = bases[idx];
         if (p.is_identity()) continue;
-        const Fp30<P> px = Fp30<P>::unpack(p.x.v);
-        Fp30<P> py = Fp30<P>::unpack(p.y.v);
+        const F30 px = F30::from_packed(p.x);
+        F30 py = F30::from_packed(p.y);
         if (v >> 31) py = py.neg2();
         acc.add_affine(px, py);
     }
     partials[t] = acc.to_std();
 }
 
-template <class P>
-__global__ void convert_bases30_kernel(Affine<Fp<P>>* __restrict__ pts, uint64_t n) {
+template <class P> G16_HD Fp<P> to_r30(const Fp<P>& x) { return Fp30<P>::std_to_r30(x); }
+template <class P> G16_HD Fp2<P> to_r30(const Fp2<P>& x) { return {Fp30<P>::std_to_r30(x.c0), Fp30<P>::std_to_r30(x.c1)}; }
+
+template <class F>
+__global__ void convert_bases30_kernel(Affine<F>* __restrict__ pts, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<Fp<P>> a = pts[i];
-    a.x = Fp30<P>::std_to_r30(a.x);  // 0 stays 0: the identity encoding (0, 0) is preserved
-    a.y = Fp30<P>::std_to_r30(a.y);
+    Affine<F> a = pts[i];
+    a.x = to_r30(a.x);  // 0 stays 0: the identity encoding (0, 0) is preserved
+    a.y = to_r30(a.y);
     pts[i] = a;
 }
 
-template <class F>
-struct AccLaunch {  // generic (G2): standard-form bases, XYZZ<F> arithmetic
-    static void launch(unsigned blocks, hipStream_t st, const Affine<F>* b, int64_t shift, uint64_t cnt, const ScalarSort& ss, uint32_t M,
-                       uint32_t lmax_log, XYZZ<F>* partials) {
-        hipLaunchKernelGGL((bucket_accumulate_kernel<F>), dim3(blocks), dim3(ACC_THREADS), 0, st, b, shift, cnt, ss.sorted, ss.offsets,
-                           ss.task_off, M, lmax_log, partials);
-    }
-};
-template <class P>
-struct AccLaunch<Fp<P>> {  // G1: R'-form bases, 30-bit lazy arithmetic
-    static void launch(unsigned blocks, hipStream_t st, const Affine<Fp<P>>* b, int64_t shift, uint64_t cnt, const ScalarSort& ss,
-                       uint32_t M, uint32_t lmax_log, XYZZ<Fp<P>>* partials) {
-        hipLaunchKernelGGL((bucket_accumulate30_kernel<P>), dim3(blocks), dim3(ACC_THREADS), 0, st, b, shift, cnt, ss.sorted, ss.offsets,
-                           ss.task_off, M, lmax_log, partials);
-    }
-};
+template <class F> struct Lazy30;
+template <class P> struct Lazy30<Fp<P>> { typedef Fp30<P> type; };
+template <class P> struct Lazy30<Fp2<P>> { typedef Fp2x30<P> type; };
 
 // ---------------------------------------------------------------------------------------------
 // 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
@@ -439,8 +430,9 @@ int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count,
     G16_TRY(arena.alloc_n((size_t)plan.W, &wsum));
     if (bucket_timer) G16_TRY(bucket_timer->start(st));
     if (ss.max_tasks) {
-        AccLaunch<F>::launch((ss.max_tasks + ACC_THREADS - 1) / ACC_THREADS, st, d_bases, shift, base_count, ss, M,
-                             (uint32_t)ilog2(plan.Lmax), partials);
+        hipLaunchKernelGGL((bucket_accumulate30_kernel<typename Lazy30<F>::type>), dim3((ss.max_tasks + ACC_THREADS - 1) / ACC_THREADS),
+                           dim3(ACC_THREADS), 0, st, d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M,
+                           (uint32_t)ilog2(plan.Lmax), partials);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));
@@ -460,10 +452,10 @@ int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count,
     return G16_OK;
 }
 
-template <class C>
-int convert_bases_g1(Affine<typename C::Fq>* d_bases, uint64_t n, hipStream_t st) {
+template <class F>
+int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st) {
     if (n == 0) return G16_OK;
-    hipLaunchKernelGGL((convert_bases30_kernel<typename C::Fq::Params>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_bases, n);
+    hipLaunchKernelGGL((convert_bases30_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_bases, n);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
@@ -479,7 +471,8 @@ XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
 }
 
 #define G16_INSTANTIATE_MSM(C)                                                                                               \
-    template int convert_bases_g1<C>(Affine<typename C::Fq>*, uint64_t, hipStream_t);                                       \
+    template int convert_bases<typename C::Fq>(Affine<typename C::Fq>*, uint64_t, hipStream_t);                             \
+    template int convert_bases<typename C::Fq2>(Affine<typename C::Fq2>*, uint64_t, hipStream_t);                           \
     template int sort_scalars<C>(const typename C::Fr*, uint64_t, Arena&, hipStream_t, ScalarSort*);                        \
     template int msm_accumulate<typename C::Fq>(const Affine<typename C::Fq>*, int64_t, uint64_t, const ScalarSort&, Arena&, \
                                                 hipStream_t, XYZZ<typename C::Fq>**, EventTimer*);                           \

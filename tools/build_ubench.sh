@@ -8,7 +8,7 @@ build() { # name, flags
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$CS -I include $2 -DG16_VARIANT="\"$1\"" tools/ubench.hip $CS/synth.hip -o tools/bin/ubench_$1 &
 }
 rm -f tools/bin/ubench_*
-build fp30_inline "-DG16_UBENCH_OPS"
-build fp30_outline "-DG16_FP30_OUTLINE"
+build default ""
+build fp2inline "-DG16_FP2X30_INLINE"
 wait
 ls -la tools/bin

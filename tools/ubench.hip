@@ -142,16 +142,17 @@ static int run_acc(const char* name, int g2) {
     return 0;
 }
 
-template <class P>
-__global__ __launch_bounds__(128) void acc30_probe(const Affine<Fp<P>>* __restrict__ bases, uint32_t nb, uint32_t len, XYZZ<Fp<P>>* __restrict__ out) {
+template <class F30>
+__global__ __launch_bounds__(128) void acc30_probe(const Affine<typename F30::Std>* __restrict__ bases, uint32_t nb, uint32_t len,
+                                                   XYZZ<typename F30::Std>* __restrict__ out) {
     const uint32_t t = blockIdx.x * 128 + threadIdx.x;
-    Acc30<P> acc = Acc30<P>::identity();
+    Acc30<F30> acc = Acc30<F30>::identity();
     uint32_t x = t * 2654435761u + 1u;
     for (uint32_t e = 0; e < len; ++e) {
         x = x * 1664525u + 1013904223u;
-        const Affine<Fp<P>> p = bases[(x >> 4) % nb];
-        const Fp30<P> px = Fp30<P>::unpack(p.x.v);
-        Fp30<P> py = Fp30<P>::unpack(p.y.v);
+        const Affine<typename F30::Std> p = bases[(x >> 4) % nb];
+        const F30 px = F30::from_packed(p.x);
+        F30 py = F30::from_packed(p.y);
         if (x & 1) py = py.neg2();
         acc.add_affine(px, py);
     }
@@ -163,6 +164,34 @@ __global__ void mul30_probe(const Fp<P>* __restrict__ in, Fp<P>* __restrict__ ou
     Fp30<P> a = Fp30<P>::unpack(in[t].v), b = Fp30<P>::unpack(in[t + 1].v);
     for (int i = 0; i < iters; ++i) { a = a.mul(b); b = b.mul(a); }
     a.add(b).canonical_lt2p().pack(out[t].v);
+}
+
+template <class C>
+static int run_acc30_g2(const char* name, int waves_per_simd) {
+    typedef typename C::Fq2 F;
+    typedef Fp2x30<typename C::Fq::Params> F30;
+    const uint32_t nb = 1 << 15, len = 48;
+    const uint32_t threads = 256 * 4 * 64 * waves_per_simd;
+    Affine<F>* d_b; XYZZ<F>* d_o;
+    CK(hipMalloc(&d_b, sizeof(Affine<F>) * nb));
+    CK(hipMalloc(&d_o, sizeof(XYZZ<F>) * threads));
+    if (synth_bases_device<C>(1, 1, 0, nb, d_b, 0) != 0) { printf("synth failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((acc30_probe<F30>), dim3(threads / 128), dim3(128), 0, 0, d_b, nb, len, d_o);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double adds = (double)threads * len;
+    printf("ACC30PROBE %-20s variant=%s waves/SIMD=%d  %.3f ms for %.0f mixed adds => %.2f Gadd/s\n", name, G16_VARIANT, waves_per_simd, ms, adds,
+           adds / ms / 1e6);
+    (void)hipFree(d_b); (void)hipFree(d_o);
+    return 0;
 }
 
 template <class C>
@@ -181,7 +210,7 @@ static int run_acc30(const char* name, int waves_per_simd) {
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((acc30_probe<P>), dim3(threads / 128), dim3(128), 0, 0, d_b, nb, len, d_o);
+        hipLaunchKernelGGL((acc30_probe<Fp30<P>>), dim3(threads / 128), dim3(128), 0, 0, d_b, nb, len, d_o);
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
     }
@@ -229,6 +258,7 @@ int main(int argc, char** argv) {
     }
 #endif
     for (int w : {1, 2}) { run_acc30<Bls12_381>("bls12_381 G1", w); run_acc30<Bn254>("bn254 G1", w); }
+    for (int w : {1, 2}) { run_acc30_g2<Bls12_381>("bls12_381 G2", w); run_acc30_g2<Bn254>("bn254 G2", w); }
 #ifdef G16_UBENCH_OPS
     run_acc<Bls12_381, Bls12_381::Fq>("bls12_381 G1", 0);
     run_acc<Bn254, Bn254::Fq>("bn254 G1", 0);
