@@ -141,6 +141,19 @@ def prove_step(p, dist, device):
     return p.finalize(parts)
 
 
+def default_cpu_threads():
+    """the GPU box's container is CPU-quota limited (cgroup cpu.max); oversubscribing the OpenMP oracle past ~2x the
+    quota collapses its throughput (measured: tools/cpu_thread_sweep.py), so use 2x quota, else all CPUs"""
+    ncpu = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, min(ncpu, int(round(2 * int(quota) / int(period)))))
+    except Exception:  # noqa: BLE001
+        pass
+    return ncpu
+
+
 def cpu_baseline(curve, k_cpu, seed, threads):
     """CPU oracle on a bounded sample: same circuit family / key shape at k_cpu; pk generated on the GPU and
     downloaded so that GPU and CPU prove the very same instance (also a parity check of this bench)."""
@@ -148,8 +161,7 @@ def cpu_baseline(curve, k_cpu, seed, threads):
     from helpers import Csr, FlatCircuit, FlatPk, oracle
 
     orc = oracle()
-    if threads:
-        orc.set_threads(threads)
+    orc.set_threads(threads or default_cpu_threads())
     dp = DeviceProver(curve, k_cpu, seed, 0, 1, torch.cuda.current_device())
     gpu_proof = dp.finalize([dp.partial()])
     rp, cols, val = dp.csr_host

@@ -565,7 +565,7 @@ struct Impl {
                 buckets[(size_t)w * plan.B + bucket].add_affine(q);
             }
         }
-        const uint32_t G = plan.B >= 32 ? 32u : plan.B, cpw = plan.B / G;
+        const uint32_t G = plan.B >= 16 ? 16u : plan.B, cpw = plan.B / G;
         std::vector<X> wsum(plan.W, X::identity());
         for (int w = 0; w < plan.W; ++w) {
             for (uint32_t ch = 0; ch < cpw; ++ch) {
@@ -661,6 +661,36 @@ struct Impl {
                 if (!(got == want)) return 100 + round * 100 + (int)i;
             }
         }
+        // ---- full additions / doublings / small multiples / packed storage of the lazy accumulator (G1)
+        {
+            typedef Acc30<F30> A30;
+            auto lift = [&](const G1X& p) { return A30::from_packed(p.is_identity() ? G1X::identity()
+                                                : G1X{F30::std_to_r30(p.x), F30::std_to_r30(p.y), F30::std_to_r30(p.zz), F30::std_to_r30(p.zzz)}); };
+            for (int it = 0; it < 12; ++it) {
+                G1X a = G1X::identity(), b = G1X::identity();
+                for (int i = 0; i < 3; ++i) { a.add_affine(pts[sm_next(st) % pts.size()]); b.add_affine(pts[sm_next(st) % pts.size()]); }
+                if (it == 1) b = a;
+                if (it == 2) b = a.neg();
+                if (it == 3) b = G1X::identity();
+                if (it == 4) a = G1X::identity();
+                A30 la = lift(a), lb = lift(b);
+                A30 sum = la; sum.add(lb);
+                G1X rs = a; rs.add(b);
+                if (!(sum.to_std().to_affine() == rs.to_affine())) return 40 + it;
+                // storage round trip keeps the group element
+                if (!(A30::from_packed(sum.to_packed()).to_std().to_affine() == rs.to_affine())) return 60 + it;
+                A30 d = la; d.dbl();
+                if (!(d.to_std().to_affine() == a.dbl().to_affine())) return 80 + it;
+                const uint32_t k = (uint32_t)(sm_next(st) % 40000u);
+                uint32_t kw[1] = {k};
+                if (!(la.mul_small(k).to_std().to_affine() == a.mul_bits(kw, 32).to_affine())) return 90;
+                // chained lazy adds (bounds must hold across many operations)
+                A30 chain = la;
+                G1X rchain = a;
+                for (int j = 0; j < 6; ++j) { chain.add(lb); rchain.add(b); chain.add(chain); rchain.add(rchain); }
+                if (!(chain.to_std().to_affine() == rchain.to_affine())) return 95;
+            }
+        }
         // ---- Fq2 over the 30-bit field, and the G2 accumulator
         typedef Fp2x30<typename Fq::Params> F230;
         for (int it = 0; it < iters / 4 + 4; ++it) {
@@ -699,6 +729,14 @@ struct Impl {
                     ref.add_affine(seq[i]);
                     if (!(acc.to_std().to_affine() == ref.to_affine())) return 1000 + round * 100 + (int)i;
                 }
+                // full add / dbl / small multiple on G2
+                Acc30<F230> other = Acc30<F230>::from_packed(acc.to_packed());
+                G2X ro = ref;
+                other.dbl(); ro = ro.dbl();
+                other.add(acc); ro.add(ref);
+                if (!(other.to_std().to_affine() == ro.to_affine())) return 2000 + round;
+                uint32_t kw[1] = {12345u + (uint32_t)round};
+                if (!(acc.mul_small(kw[0]).to_std().to_affine() == ref.mul_bits(kw, 32).to_affine())) return 2100 + round;
             }
         }
         return 0;

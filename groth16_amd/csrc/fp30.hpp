@@ -180,6 +180,12 @@ struct Fp30 {
         return r;
     }
 
+    // lazy value (< 16p) -> canonical x*R' packed in words (the kernels' own storage form)
+    G16_HD Std to_packed() const {
+        Std r;
+        mul_impl(one()).canonical_lt2p().pack(r.v);  // x R' * R' / R' = x R', now < 1.5p -> exact
+        return r;
+    }
     // conversions to / from the standard arkworks Montgomery form (x*R mod p, 32-bit words)
     // std -> packed R' form: one standard product by the plain integer R' mod p
     G16_HD static Fp<P> std_to_r30(const Fp<P>& x) {
@@ -237,14 +243,14 @@ struct Fp2x30 {
     G16_HD_NOINLINE static Fp2x30 mul_outlined(const Fp2x30& a, const Fp2x30& b) { return a.mul_impl(b); }
     G16_HD_NOINLINE static Fp2x30 sqr_outlined(const Fp2x30& a) { return a.sqr_impl(); }
     G16_HD Fp2x30 mul(const Fp2x30& o) const {
-#ifdef G16_FP2X30_INLINE
+#ifndef G16_FP2X30_OUTLINE
         return mul_impl(o);
 #else
         return mul_outlined(*this, o);
 #endif
     }
     G16_HD Fp2x30 sqr() const {
-#ifdef G16_FP2X30_INLINE
+#ifndef G16_FP2X30_OUTLINE
         return sqr_impl();
 #else
         return sqr_outlined(*this);
@@ -253,6 +259,7 @@ struct Fp2x30 {
     G16_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
     G16_HD bool is_zero_exact() const { return c0.is_zero_exact() && c1.is_zero_exact(); }
     G16_HD Std to_std() const { return {c0.to_std(), c1.to_std()}; }
+    G16_HD Std to_packed() const { return {c0.to_packed(), c1.to_packed()}; }
 };
 
 // Lazy extended-Jacobian accumulator, F = Fp30<P> (G1) or Fp2x30<P> (G2).  Invariants between calls
@@ -311,7 +318,70 @@ struct Acc30 {
         zz = zz.mul(PP);
         zzz = zzz.mul(PPP);
     }
-    // leave the kernel: standard-form XYZZ (canonical coordinates)
+    // dbl-2008-s-1
+    G16_HD void dbl() {
+        if (inf) return;
+        const F U = y.dbl();                      // < 7p
+        if (U.is_zero_exact()) { inf = true; return; }
+        const F V = U.sqr();
+        const F W = U.mul(V);
+        const F S = x.mul(V);
+        const F X2 = x.sqr();
+        const F M = X2.dbl().add(X2);             // < 4.5p
+        const F X3 = M.sqr().template sub<4>(S.dbl());                       // < 5.5p
+        const F Y3 = M.mul(S.template sub<8>(X3)).template sub<2>(W.mul(y));  // < 3.5p
+        x = X3; y = Y3;
+        zz = V.mul(zz);
+        zzz = W.mul(zzz);
+    }
+    // add-2008-s: this += o
+    G16_HD void add(const Acc30& o) {
+        if (o.inf) return;
+        if (inf) { *this = o; return; }
+        const F U1 = x.mul(o.zz);                 // all < 1.5p
+        const F U2 = o.x.mul(zz);
+        const F S1 = y.mul(o.zzz);
+        const F S2 = o.y.mul(zzz);
+        const F Pd = U2.template sub<2>(U1);      // < 3.5p
+        const F R = S2.template sub<2>(S1);
+        if (Pd.maybe_zero()) {
+            if (Pd.is_zero_exact()) {
+                if (R.is_zero_exact()) dbl();
+                else inf = true;
+                return;
+            }
+        }
+        const F PP = Pd.sqr();
+        const F PPP = Pd.mul(PP);
+        const F Q = U1.mul(PP);
+        const F X3 = R.sqr().template sub<2>(PPP).template sub<4>(Q.dbl());       // < 7.5p
+        const F Y3 = R.mul(Q.template sub<8>(X3)).template sub<2>(S1.mul(PPP));   // < 3.5p
+        x = X3;
+        y = Y3;
+        zz = zz.mul(o.zz).mul(PP);
+        zzz = zzz.mul(o.zzz).mul(PPP);
+    }
+    // k * this for a small scalar (double-and-add, MSB first)
+    G16_HD Acc30 mul_small(uint32_t k) const {
+        Acc30 acc = identity();
+        for (int i = 31; i >= 0; --i) {
+            acc.dbl();
+            if ((k >> i) & 1) acc.add(*this);
+        }
+        return acc;
+    }
+    // storage form between kernels: canonical coordinates in the R' domain packed in words; identity = all zero
+    G16_HD XYZZ<StdF> to_packed() const {
+        if (inf) return XYZZ<StdF>::identity();
+        return {x.to_packed(), y.to_packed(), zz.to_packed(), zzz.to_packed()};
+    }
+    G16_HD static Acc30 from_packed(const XYZZ<StdF>& p) {
+        Acc30 a;
+        a.inf = p.zz.is_zero();
+        a.x = F::from_packed(p.x); a.y = F::from_packed(p.y); a.zz = F::from_packed(p.zz); a.zzz = F::from_packed(p.zzz);
+        return a;
+    }
+    // leave the device: standard-form XYZZ (canonical coordinates, arkworks Montgomery radix)
     G16_HD XYZZ<StdF> to_std() const {
         if (inf) return XYZZ<StdF>::identity();
         return {x.to_std(), y.to_std(), zz.to_std(), zzz.to_std()};

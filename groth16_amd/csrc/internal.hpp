@@ -124,6 +124,7 @@ struct ScalarSort {
     uint32_t* sorted = nullptr;    // [<= n*W] point index | sign<<31, grouped by (window, bucket)
     uint32_t* offsets = nullptr;   // [W*B + 1] exclusive prefix of bucket sizes
     uint32_t* task_off = nullptr;  // [W*B + 1] exclusive prefix of per-bucket task counts
+    uint32_t* heavy = nullptr;     // [0] = number of buckets split over several tasks, then their ids
     uint32_t max_tasks = 0;        // host-side upper bound on task_off[W*B]
 };
 template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipStream_t st, ScalarSort* out);

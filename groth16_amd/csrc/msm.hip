@@ -38,6 +38,7 @@ namespace g16 {
 static constexpr int SORT_THREADS = 1024;
 static constexpr int ACC_THREADS = 128;
 static constexpr int RED_THREADS = 64;
+static constexpr uint32_t REDUCE_G = 16;  // buckets per lane in the bucket reduction
 
 struct PlanDev {
     int c, W;
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const uint16
 // 3. scan (single workgroup; M = W*B <= 2^19 entries)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* __restrict__ counts, uint32_t M, uint32_t lmax_log,
-                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ task_off) {
+                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ task_off,
+                                                           uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
     __shared__ uint32_t sa[1024], sb[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t seg = (M + 1023) / 1024;
@@ -128,6 +130,8 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* __res
         task_off[i] = baseB;
         baseA += v;
         baseB += (v + lmask) >> lmax_log;
+        // a bucket split over several tasks needs its partial sums combined before the bucket reduction
+        if (v > (1u << lmax_log)) heavy[1 + atomicAdd(&heavy[0], 1u)] = i;
     }
     if (tid == 1023) {
         offsets[M] = sa[1023];
@@ -202,8 +206,9 @@ __global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate_kernel(const Af
 }
 
 // Production variant on the 30-bit lazy arithmetic (fp30.hpp), F30 = Fp30<P> (G1) or Fp2x30<P> (G2).
-// `bases` hold canonical x*R', y*R' packed in 32-bit words (convert_bases30_kernel); partial sums
-// leave in the standard Montgomery form so the reduction kernels and the host are unaffected.
+// `bases` hold canonical x*R', y*R' packed in 32-bit words (convert_bases30_kernel); partial sums are
+// stored in the same R' domain (XYZZ, canonical, packed) and only the W window sums are converted to
+// the standard arkworks radix for the host.
 template <class F30>
 __global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate30_kernel(const Affine<typename F30::Std>* __restrict__ bases,
                                                                           int64_t shift, uint64_t base_count,
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate30_kernel(const 
         if (v >> 31) py = py.neg2();
         acc.add_affine(px, py);
     }
-    partials[t] = acc.to_std();
+    partials[t] = acc.to_packed();
 }
 
 template <class P> G16_HD Fp<P> to_r30(const Fp<P>& x) { return Fp30<P>::std_to_r30(x); }
@@ -255,51 +260,83 @@ template <class P> struct Lazy30<Fp<P>> { typedef Fp30<P> type; };
 template <class P> struct Lazy30<Fp2<P>> { typedef Fp2x30<P> type; };
 
 // ---------------------------------------------------------------------------------------------
+// 5b. heavy buckets: a bucket that was split over several tasks (short top window, repeated
+//     scalars such as the all-equal witness of benches/bench.rs:52-54, ...) has its partial sums
+//     combined cooperatively by one workgroup; the result replaces the bucket's first partial.
+// ---------------------------------------------------------------------------------------------
+static constexpr int HEAVY_THREADS = 128;
+static constexpr int HEAVY_BLOCKS = 512;
+
+template <class F30>
+__global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(XYZZ<typename F30::Std>* __restrict__ partials,
+                                                                     const uint32_t* __restrict__ task_off,
+                                                                     const uint32_t* __restrict__ heavy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<typename F30::Std>* sh = reinterpret_cast<XYZZ<typename F30::Std>*>(smem);
+    const uint32_t nheavy = heavy[0], tid = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < nheavy; i += gridDim.x) {
+        const uint32_t b = heavy[1 + i];
+        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        Acc30<F30> acc = Acc30<F30>::identity();
+        for (uint32_t q = t0 + tid; q < t1; q += HEAVY_THREADS) acc.add(Acc30<F30>::from_packed(partials[q]));
+        __syncthreads();  // previous iteration's readers are done with sh / partials[t0]
+        sh[tid] = acc.to_packed();
+        __syncthreads();
+        for (uint32_t d = HEAVY_THREADS / 2; d > 0; d >>= 1) {
+            if (tid < d) {
+                Acc30<F30> x = Acc30<F30>::from_packed(sh[tid]);
+                x.add(Acc30<F30>::from_packed(sh[tid + d]));
+                sh[tid] = x.to_packed();
+            }
+            __syncthreads();
+        }
+        if (tid == 0) partials[t0] = sh[0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
 // ---------------------------------------------------------------------------------------------
-template <class F>
-__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const XYZZ<F>* __restrict__ partials,
+template <class F30>
+__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const XYZZ<typename F30::Std>* __restrict__ partials,
                                                                     const uint32_t* __restrict__ task_off, uint32_t B, int W,
-                                                                    uint32_t G, XYZZ<F>* __restrict__ chunk_out) {
+                                                                    uint32_t G, XYZZ<typename F30::Std>* __restrict__ chunk_out) {
     const uint32_t cpw = B / G;
     const uint32_t t = blockIdx.x * RED_THREADS + threadIdx.x;
     if (t >= cpw * (uint32_t)W) return;
     const uint32_t w = t / cpw, ch = t % cpw, b_lo = ch * G;
-    XYZZ<F> run = XYZZ<F>::identity(), tot = XYZZ<F>::identity();
+    Acc30<F30> run = Acc30<F30>::identity(), tot = Acc30<F30>::identity();
     for (uint32_t bb = G; bb-- > 0;) {
         const uint32_t gb = w * B + b_lo + bb;
         const uint32_t t0 = task_off[gb], t1 = task_off[gb + 1];
-        for (uint32_t q = t0; q < t1; ++q) run.add(partials[q]);
+        if (t1 > t0) run.add(Acc30<F30>::from_packed(partials[t0]));  // multi-task buckets were pre-combined into [t0]
         tot.add(run);
     }
     // sum_b (b+1) S_b over the chunk = tot + b_lo * run
-    if (b_lo) {
-        uint32_t kk[1] = {b_lo};
-        XYZZ<F> m = run.mul_bits(kk, 32 - __clz(b_lo));
-        tot.add(m);
-    }
-    chunk_out[t] = tot;
+    if (b_lo) tot.add(run.mul_small(b_lo));
+    chunk_out[t] = tot.to_packed();
 }
 
-template <class F>
-__global__ __launch_bounds__(RED_THREADS) void window_reduce_kernel(const XYZZ<F>* __restrict__ chunk_out, uint32_t cpw,
-                                                                    XYZZ<F>* __restrict__ window_sums) {
+template <class F30>
+__global__ __launch_bounds__(RED_THREADS) void window_reduce_kernel(const XYZZ<typename F30::Std>* __restrict__ chunk_out, uint32_t cpw,
+                                                                    XYZZ<typename F30::Std>* __restrict__ window_sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    XYZZ<typename F30::Std>* sh = reinterpret_cast<XYZZ<typename F30::Std>*>(smem);
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
-    XYZZ<F> acc = XYZZ<F>::identity();
-    for (uint32_t j = tid; j < cpw; j += RED_THREADS) acc.add(chunk_out[(uint64_t)w * cpw + j]);
-    sh[tid] = acc;
+    Acc30<F30> acc = Acc30<F30>::identity();
+    for (uint32_t j = tid; j < cpw; j += RED_THREADS) acc.add(Acc30<F30>::from_packed(chunk_out[(uint64_t)w * cpw + j]));
+    sh[tid] = acc.to_packed();
     __syncthreads();
     for (uint32_t d = RED_THREADS / 2; d > 0; d >>= 1) {
         if (tid < d) {
-            XYZZ<F> a = sh[tid];
-            a.add(sh[tid + d]);
-            sh[tid] = a;
+            Acc30<F30> x = Acc30<F30>::from_packed(sh[tid]);
+            x.add(Acc30<F30>::from_packed(sh[tid + d]));
+            sh[tid] = x.to_packed();
         }
         __syncthreads();
     }
-    if (tid == 0) window_sums[w] = sh[0];
+    // the W window sums are what leaves the device: standard arkworks Montgomery radix
+    if (tid == 0) window_sums[w] = Acc30<F30>::from_packed(sh[0]).to_std();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,17 +347,11 @@ int msm_window_override() {
     return e ? atoi(e) : 0;
 }
 
-int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, MsmPlan* plan) {
-    int lg = 0;
-    while (((uint64_t)2 << lg) <= n) ++lg;  // floor(log2 n), 0 for n <= 1
-    int c = msm_window_override();
-    if (c <= 0) c = lg - 5;
-    if (c < 3) c = 3;
-    if (c > 16) c = 16;
+// W for a given c: smallest W with (modulus - 1) + K < 2^(cW)
+static int plan_windows(int c, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, uint32_t* Kout) {
     int W = (scalar_bits + 1 + c - 1) / c;
     for (;; ++W) {
-        // K = sum_w 2^(c-1) 2^(cw); need (modulus - 1) + K < 2^(cW) and cW <= 32*10
-        if (c * W > 320) return G16_ERR_INTERNAL;
+        if (c * W > 320) return -1;
         uint32_t K[MSM_SWORDS] = {0};
         for (int w = 0; w < W; ++w) {
             const int bit = w * c + c - 1;
@@ -333,19 +364,41 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
             sum[k] = (uint32_t)carry;
             carry >>= 32;
         }
-        // sum = modulus + K  >  (modulus - 1) + K ; require sum <= 2^(cW)  (conservative by one)
-        bool ok = true;
-        const int top = c * W;
-        for (int bit = MSM_SWORDS * 32 - 1; bit >= top; --bit)
+        bool ok = true;  // sum = modulus + K > (modulus - 1) + K ; require sum < 2^(cW)  (conservative by one)
+        for (int bit = MSM_SWORDS * 32 - 1; bit >= c * W; --bit)
             if ((sum[bit >> 5] >> (bit & 31)) & 1) { ok = false; break; }
         if (ok) {
-            plan->c = c;
-            plan->W = W;
-            plan->B = 1u << (c - 1);
-            for (int k = 0; k < 10; ++k) plan->K[k] = K[k];
-            break;
+            if (Kout) for (int k = 0; k < 10; ++k) Kout[k] = K[k];
+            return W;
         }
     }
+}
+
+int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, MsmPlan* plan) {
+    int c = msm_window_override();
+    if (c <= 0) {
+        // cost model (seconds, MI355X measurements of round 1): the bucket pass folds n*W points at ~4.5 G mixed adds/s;
+        // the bucket reduction is W*B/G lanes of (2G + ~24) dependent full additions, latency-bound (~12 us each) until
+        // the lanes exceed two waves per SIMD.
+        double best = 1e300;
+        for (int cc = 4; cc <= 16; ++cc) {
+            const int W = plan_windows(cc, scalar_bits, modulus_words, mod_nwords, nullptr);
+            if (W < 0) continue;
+            const double B = (double)(1u << (cc - 1));
+            const double acc = (double)n * W / 4.5e9;
+            const double lanes = W * B / REDUCE_G;
+            const double red = (2.0 * REDUCE_G + 24.0) * 12e-6 * (lanes > 131072.0 ? lanes / 131072.0 : 1.0);
+            const double launch = 4e-6 * W;  // per-window bookkeeping
+            if (acc + red + launch < best) { best = acc + red + launch; c = cc; }
+        }
+    }
+    if (c < 3) c = 3;
+    if (c > 16) c = 16;
+    const int W = plan_windows(c, scalar_bits, modulus_words, mod_nwords, plan->K);
+    if (W < 0) return G16_ERR_INTERNAL;
+    plan->c = c;
+    plan->W = W;
+    plan->B = 1u << (c - 1);
     // task granularity: ~2x the mean bucket load, power of two, >= 32
     uint64_t mean = n / plan->B + 1;
     uint32_t l = 32;
@@ -379,13 +432,14 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
     uint16_t* planes = nullptr;
     uint32_t *counts = nullptr, *cursor = nullptr;
     G16_TRY(arena.alloc_n(nw ? nw : 1, &planes));
-    G16_TRY(arena.alloc_n((size_t)2 * M, &counts));
+    G16_TRY(arena.alloc_n((size_t)3 * M + 1, &counts));  // counts | scatter cursors | heavy count + list
     cursor = counts + M;
+    out->heavy = counts + 2 * (size_t)M;
     G16_TRY(arena.alloc_n((size_t)M + 1, &out->offsets));
     G16_TRY(arena.alloc_n((size_t)M + 1, &out->task_off));
     G16_TRY(arena.alloc_n(nw ? nw : 1, &out->sorted));
     out->max_tasks = (uint32_t)(nw / plan.Lmax) + M;
-    G16_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)2 * M * sizeof(uint32_t), st));
+    G16_HIP_TRY(hipMemsetAsync(counts, 0, ((size_t)2 * M + 1) * sizeof(uint32_t), st));
     PlanDev pd;
     pd.c = plan.c; pd.W = plan.W; pd.B = plan.B;
     for (int k = 0; k < 10; ++k) pd.K[k] = plan.K[k];
@@ -406,7 +460,8 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
                            counts);
         G16_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, counts, M, (uint32_t)ilog2(plan.Lmax), out->offsets, out->task_off);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, counts, M, (uint32_t)ilog2(plan.Lmax), out->offsets, out->task_off,
+                       out->heavy);
     G16_LAUNCH_CHECK();
     if (n) {
         const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
@@ -420,9 +475,10 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
 template <class F>
 int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena, hipStream_t st,
                    XYZZ<F>** d_window_sums, EventTimer* bucket_timer) {
+    typedef typename Lazy30<F>::type F30;
     const MsmPlan& plan = ss.plan;
     const uint32_t M = plan.B * (uint32_t)plan.W;
-    const uint32_t G = plan.B >= 32 ? 32u : plan.B;
+    const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
     XYZZ<F>*partials = nullptr, *chunk_out = nullptr, *wsum = nullptr;
     G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
@@ -430,23 +486,24 @@ int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count,
     G16_TRY(arena.alloc_n((size_t)plan.W, &wsum));
     if (bucket_timer) G16_TRY(bucket_timer->start(st));
     if (ss.max_tasks) {
-        hipLaunchKernelGGL((bucket_accumulate30_kernel<typename Lazy30<F>::type>), dim3((ss.max_tasks + ACC_THREADS - 1) / ACC_THREADS),
-                           dim3(ACC_THREADS), 0, st, d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M,
-                           (uint32_t)ilog2(plan.Lmax), partials);
+        hipLaunchKernelGGL((bucket_accumulate30_kernel<F30>), dim3((ss.max_tasks + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, st,
+                           d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), partials);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));
-    hipLaunchKernelGGL((bucket_reduce_kernel<F>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, partials,
-                       ss.task_off, plan.B, plan.W, G, chunk_out);
-    G16_LAUNCH_CHECK();
     static bool attr_set = false;
-    const size_t lds = sizeof(XYZZ<F>) * RED_THREADS;
-    if (!attr_set && lds > 48 * 1024) {
-        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_reduce_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
+    const size_t lds_heavy = sizeof(XYZZ<F>) * HEAVY_THREADS, lds_win = sizeof(XYZZ<F>) * RED_THREADS;
+    if (!attr_set) {
+        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&heavy_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_heavy));
         attr_set = true;
     }
-    hipLaunchKernelGGL((window_reduce_kernel<F>), dim3(plan.W), dim3(RED_THREADS), lds, st, chunk_out, cpw, wsum);
+    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, partials, ss.task_off, ss.heavy);
+    G16_LAUNCH_CHECK();
+    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, partials,
+                       ss.task_off, plan.B, plan.W, G, chunk_out);
+    G16_LAUNCH_CHECK();
+    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.W), dim3(RED_THREADS), lds_win, st, chunk_out, cpw, wsum);
     G16_LAUNCH_CHECK();
     *d_window_sums = wsum;
     return G16_OK;
