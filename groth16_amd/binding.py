@@ -8,7 +8,7 @@ from typing import Optional
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libg16_mi355x.so")
+LIB_PATH = os.environ.get("G16_LIB", os.path.join(HERE, "libg16_mi355x.so"))  # G16_LIB: A/B-test another build
 
 CURVE_ID = {"bls12_381": 0, "bn254": 1}
 FQ_LIMBS = {"bls12_381": 6, "bn254": 4}

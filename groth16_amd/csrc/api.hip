@@ -58,10 +58,14 @@ using namespace g16;
 struct g16_ctx {
     int curve;
     int device;
-    hipStream_t stream;
+    hipStream_t stream;   // bucket passes, digit/sort
+    hipStream_t stream2;  // witness map and the latency-bound reductions, underneath the bucket passes
     Arena arena;
     g16_timings tm;
-    EventTimer t_wm, t_prep_h, t_prep_z, t_msm[5], t_bucket[5];
+    EventTimer t_wm, t_prep_h, t_prep_z, t_bucket[5];
+    hipEvent_t ev_z = nullptr, ev_h = nullptr, ev_acc[5] = {}, ev_done[5] = {}, ev_msm_start[5] = {};
+    void* pinned = nullptr;  // window sums land here (hipHostMalloc)
+    size_t pinned_bytes = 0;
 };
 
 struct g16_circuit {
@@ -240,7 +244,7 @@ struct Impl {
                              int skip_b_g1, g16_partial* out) {
         const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
         const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
-        hipStream_t st = ctx->stream;
+        hipStream_t s1 = ctx->stream, s2 = ctx->stream2;
         if (n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
         const uint64_t n = ck->dom->n, nin = ck->num_inputs;
         const uint64_t m = n_assign - 1, w = n_assign - nin;
@@ -255,88 +259,108 @@ struct Impl {
         ctx->arena.reset();
         const Fr* d_z = nullptr;
         G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));
 
-        // ---- witness map: h = QAP::witness_map_from_matrices (prover.rs:37-42)
+        // ---- stream 2: witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it
         Fr* d_h = nullptr;
         G16_TRY(ctx->arena.alloc_n(n, &d_h));
-        G16_TRY(ctx->t_wm.start(st));
-        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, st)));
-        G16_TRY(ctx->t_wm.stop(st));
+        G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
+        G16_TRY(ctx->t_wm.start(s2));
+        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s2)));
+        G16_TRY(ctx->t_wm.stop(s2));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_h, s2));
 
-        // ---- h_acc = msm(h_query, h) (prover.rs:63-66)
+        // ---- stream 1: assignment = full_assignment[1..] (prover.rs:80-85): ONE digit/sort pass for a, b_g1, b_g2 (and l)
         ScalarSort sort_h, sort_z, sort_l;
-        G1X *ws_h = nullptr, *ws_l = nullptr, *ws_a = nullptr, *ws_b1 = nullptr;
-        G2X* ws_b2 = nullptr;
-        G16_TRY(ctx->t_prep_h.start(st));
-        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, st, &sort_h)));
-        G16_TRY(ctx->t_prep_h.stop(st));
-        G16_TRY(ctx->t_msm[0].start(st));
-        G16_TRY((msm_accumulate<Fq>(pk->h, 0, pk->h_count, sort_h, ctx->arena, st, &ws_h, &ctx->t_bucket[0])));
-        G16_TRY(ctx->t_msm[0].stop(st));
+        G16_TRY(ctx->t_prep_z.start(s1));
+        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, ctx->arena, s1, &sort_z)));
+        G16_TRY(ctx->t_prep_z.stop(s1));
 
-        // ---- assignment = full_assignment[1..] (prover.rs:80-85): one digit/sort pass for a, b_g1, b_g2 (and l)
-        G16_TRY(ctx->t_prep_z.start(st));
-        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, ctx->arena, st, &sort_z)));
-        G16_TRY(ctx->t_prep_z.stop(st));
+        MsmBuffers<Fq> buf_h, buf_l, buf_a, buf_b1;
+        MsmBuffers<Fq2> buf_b2;
+        // window sums of MSM k land in the pinned host buffer; slot layout by MSM order (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2)
+        const size_t SLOT = 96 * sizeof(G2X);  // W <= 86 for every admissible window size
+        if (ctx->pinned_bytes < 5 * SLOT) {
+            if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+            G16_HIP_TRY(hipHostMalloc(&ctx->pinned, 5 * SLOT, hipHostMallocDefault));
+            ctx->pinned_bytes = 5 * SLOT;
+        }
+        char* pin = static_cast<char*>(ctx->pinned);
+        if (sort_z.plan.W > 96) return G16_ERR_INTERNAL;
+        // bucket pass on stream 1; reduction + copy-out on stream 2
+        auto run_msm = [&](int k, auto* bases, int64_t shift, uint64_t count, const ScalarSort& ss, auto* buf) -> int {
+            typedef typename std::remove_pointer<decltype(buf)>::type Buf;
+            G16_HIP_TRY(hipEventRecord(ctx->ev_msm_start[k], s1));
+            G16_TRY((msm_bucket_pass(bases, shift, count, ss, ctx->arena, s1, buf, &ctx->t_bucket[k])));
+            G16_HIP_TRY(hipEventRecord(ctx->ev_acc[k], s1));
+            G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_acc[k], 0));
+            G16_TRY((msm_reduce(*buf, ss, s2)));
+            G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf->window_sums, sizeof(*Buf().window_sums) * ss.plan.W, hipMemcpyDeviceToHost, s2));
+            G16_HIP_TRY(hipEventRecord(ctx->ev_done[k], s2));
+            return G16_OK;
+        };
 
         // l_aux_acc = msm(l_query, aux) (prover.rs:70-74); aux[j] = assignment[j + nin - 1]
         const bool l_covered = pk->l_count == 0 || (pk->l_start + nin - 1 >= pk->a_start &&
                                                     pk->l_start + pk->l_count + nin - 1 <= pk->a_start + pk->a_count);
-        G16_TRY(ctx->t_msm[1].start(st));
+        // the G2 MSM goes first: its reduction is the longest and hides under the G1 bucket passes
+        G16_TRY(run_msm(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2));                                   // prover.rs:113
         if (l_covered) {
             const int64_t shift = (int64_t)pk->a_start - (int64_t)(nin - 1) - (int64_t)pk->l_start;
-            G16_TRY((msm_accumulate<Fq>(pk->l, shift, pk->l_count, sort_z, ctx->arena, st, &ws_l, &ctx->t_bucket[1])));
+            G16_TRY(run_msm(1, pk->l, shift, pk->l_count, sort_z, &buf_l));
         } else {
-            G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, ctx->arena, st, &sort_l)));
-            G16_TRY((msm_accumulate<Fq>(pk->l, 0, pk->l_count, sort_l, ctx->arena, st, &ws_l, &ctx->t_bucket[1])));
+            G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, ctx->arena, s1, &sort_l)));
+            G16_TRY(run_msm(1, pk->l, 0, pk->l_count, sort_l, &buf_l));
         }
-        G16_TRY(ctx->t_msm[1].stop(st));
-        G16_TRY(ctx->t_msm[2].start(st));
-        G16_TRY((msm_accumulate<Fq>(pk->a, 0, pk->a_count, sort_z, ctx->arena, st, &ws_a, &ctx->t_bucket[2])));  // prover.rs:92
-        G16_TRY(ctx->t_msm[2].stop(st));
-        ctx->t_msm[3].used = false;
+        G16_TRY(run_msm(2, pk->a, 0, pk->a_count, sort_z, &buf_a));                                          // prover.rs:92
         ctx->t_bucket[3].used = false;
-        if (!skip_b_g1) {  // prover.rs:98-108
-            G16_TRY(ctx->t_msm[3].start(st));
-            G16_TRY((msm_accumulate<Fq>(pk->b_g1, 0, pk->b_g1_count, sort_z, ctx->arena, st, &ws_b1, &ctx->t_bucket[3])));
-            G16_TRY(ctx->t_msm[3].stop(st));
-        }
-        G16_TRY(ctx->t_msm[4].start(st));
-        G16_TRY((msm_accumulate<Fq2>(pk->b_g2, 0, pk->b_g2_count, sort_z, ctx->arena, st, &ws_b2, &ctx->t_bucket[4])));  // prover.rs:113
-        G16_TRY(ctx->t_msm[4].stop(st));
+        if (!skip_b_g1) G16_TRY(run_msm(3, pk->b_g1, 0, pk->b_g1_count, sort_z, &buf_b1));                  // prover.rs:98-108
+        // ---- h_acc = msm(h_query, h) (prover.rs:63-66): needs the witness map
+        G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_h, 0));
+        G16_TRY(ctx->t_prep_h.start(s1));
+        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, s1, &sort_h)));
+        G16_TRY(ctx->t_prep_h.stop(s1));
+        G16_TRY(run_msm(0, pk->h, 0, pk->h_count, sort_h, &buf_h));
 
-        // ---- window sums -> host, fold
-        const MsmPlan& ph = sort_h.plan;
-        const MsmPlan& pz = sort_z.plan;
-        const MsmPlan& pl = l_covered ? sort_z.plan : sort_l.plan;
-        std::vector<G1X> hws_h(ph.W), hws_l(pl.W), hws_a(pz.W), hws_b1(pz.W);
-        std::vector<G2X> hws_b2(pz.W);
-        G16_HIP_TRY(hipMemcpyAsync(hws_h.data(), ws_h, sizeof(G1X) * ph.W, hipMemcpyDeviceToHost, st));
-        G16_HIP_TRY(hipMemcpyAsync(hws_l.data(), ws_l, sizeof(G1X) * pl.W, hipMemcpyDeviceToHost, st));
-        G16_HIP_TRY(hipMemcpyAsync(hws_a.data(), ws_a, sizeof(G1X) * pz.W, hipMemcpyDeviceToHost, st));
-        if (!skip_b_g1) G16_HIP_TRY(hipMemcpyAsync(hws_b1.data(), ws_b1, sizeof(G1X) * pz.W, hipMemcpyDeviceToHost, st));
-        G16_HIP_TRY(hipMemcpyAsync(hws_b2.data(), ws_b2, sizeof(G2X) * pz.W, hipMemcpyDeviceToHost, st));
-        G16_HIP_TRY(hipStreamSynchronize(st));
-        const double t_fold = now_ms();
-        store_xyzz(out->h, fold_windows<Fq>(hws_h.data(), ph));
-        store_xyzz(out->l, fold_windows<Fq>(hws_l.data(), pl));
-        store_xyzz(out->a, fold_windows<Fq>(hws_a.data(), pz));
-        if (!skip_b_g1) store_xyzz(out->b_g1, fold_windows<Fq>(hws_b1.data(), pz));
+        // ---- host: fold sum_w 2^(cw) R_w per MSM as its window sums arrive (the GPU is still busy with later MSMs)
+        double fold_ms = 0.0;
+        auto fold_g1 = [&](int k, const MsmPlan& plan, uint64_t* dst) -> int {
+            G16_HIP_TRY(hipEventSynchronize(ctx->ev_done[k]));
+            const double t0 = now_ms();
+            store_xyzz(dst, fold_windows<Fq>(reinterpret_cast<const G1X*>(pin + k * SLOT), plan));
+            fold_ms += now_ms() - t0;
+            return G16_OK;
+        };
+        {
+            G16_HIP_TRY(hipEventSynchronize(ctx->ev_done[4]));
+            const double t0 = now_ms();
+            store_xyzz(out->b_g2, fold_windows<Fq2>(reinterpret_cast<const G2X*>(pin + 4 * SLOT), sort_z.plan));
+            fold_ms += now_ms() - t0;
+        }
+        G16_TRY(fold_g1(1, l_covered ? sort_z.plan : sort_l.plan, out->l));
+        G16_TRY(fold_g1(2, sort_z.plan, out->a));
+        if (!skip_b_g1) G16_TRY(fold_g1(3, sort_z.plan, out->b_g1));
         else store_xyzz(out->b_g1, G1X::identity());
-        store_xyzz(out->b_g2, fold_windows<Fq2>(hws_b2.data(), pz));
+        G16_TRY(fold_g1(0, sort_h.plan, out->h));
+        G16_HIP_TRY(hipStreamSynchronize(s1));
+        G16_HIP_TRY(hipStreamSynchronize(s2));
         const double t_end = now_ms();
 
         g16_timings& tm = ctx->tm;
         memset(&tm, 0, sizeof(tm));
+        auto span = [&](int k) -> double {  // bucket pass start (stream 1) -> window sums on the host (stream 2)
+            float t = 0.f;
+            return hipEventElapsedTime(&t, ctx->ev_msm_start[k], ctx->ev_done[k]) == hipSuccess ? (double)t : 0.0;
+        };
         tm.witness_map_ms = ctx->t_wm.ms();
         tm.scalar_prep_ms = ctx->t_prep_h.ms() + ctx->t_prep_z.ms();
-        tm.msm_h_ms = ctx->t_msm[0].ms();
-        tm.msm_l_ms = ctx->t_msm[1].ms();
-        tm.msm_a_ms = ctx->t_msm[2].ms();
-        tm.msm_b_g1_ms = ctx->t_msm[3].ms();
-        tm.msm_b_g2_ms = ctx->t_msm[4].ms();
+        tm.msm_h_ms = span(0);
+        tm.msm_l_ms = span(1);
+        tm.msm_a_ms = span(2);
+        tm.msm_b_g1_ms = skip_b_g1 ? 0.0 : span(3);
+        tm.msm_b_g2_ms = span(4);
         for (int i = 0; i < 5; ++i) { tm.bucket_ms[i] = ctx->t_bucket[i].ms(); tm.bucket_pass_ms += tm.bucket_ms[i]; }
-        tm.finish_ms = t_end - t_fold;
+        tm.finish_ms = fold_ms;
         tm.total_ms = t_end - t_begin;
         return G16_OK;
     }
@@ -432,10 +456,11 @@ struct Impl {
         G16_TRY((convert_bases<F>(d_b, n, st)));
         ScalarSort ss;
         G16_TRY((sort_scalars<C>(d_s, n, ctx->arena, st, &ss)));
-        X* ws = nullptr;
-        G16_TRY((msm_accumulate<F>(d_b, 0, n, ss, ctx->arena, st, &ws, &ctx->t_bucket[0])));
+        MsmBuffers<F> buf;
+        G16_TRY((msm_bucket_pass<F>(d_b, 0, n, ss, ctx->arena, st, &buf, &ctx->t_bucket[0])));
+        G16_TRY((msm_reduce<F>(buf, ss, st)));
         std::vector<X> hws(ss.plan.W);
-        G16_HIP_TRY(hipMemcpyAsync(hws.data(), ws, sizeof(X) * ss.plan.W, hipMemcpyDeviceToHost, st));
+        G16_HIP_TRY(hipMemcpyAsync(hws.data(), buf.window_sums, sizeof(X) * ss.plan.W, hipMemcpyDeviceToHost, st));
         G16_HIP_TRY(hipStreamSynchronize(st));
         const A res = fold_windows<F>(hws.data(), ss.plan).to_affine();
         memcpy(out_affine, &res, sizeof(A));
@@ -774,7 +799,15 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
     c->curve = curve;
     c->device = device_id;
     memset(&c->tm, 0, sizeof(c->tm));
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < 5; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming) == hipSuccess && hipEventCreate(&c->ev_done[i]) == hipSuccess &&
+             hipEventCreate(&c->ev_msm_start[i]) == hipSuccess;
+    if (!ok) {
+        g16::set_last_error("stream/event creation", hipGetLastError(), __FILE__, __LINE__);
         delete c;
         return G16_ERR_HIP;
     }
@@ -786,10 +819,17 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
     ctx->arena.release();
     ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy();
-    for (int i = 0; i < 5; ++i) { ctx->t_msm[i].destroy(); ctx->t_bucket[i].destroy(); }
+    for (int i = 0; i < 5; ++i) {
+        ctx->t_bucket[i].destroy();
+        (void)hipEventDestroy(ctx->ev_acc[i]); (void)hipEventDestroy(ctx->ev_done[i]); (void)hipEventDestroy(ctx->ev_msm_start[i]);
+    }
+    (void)hipEventDestroy(ctx->ev_z); (void)hipEventDestroy(ctx->ev_h);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 

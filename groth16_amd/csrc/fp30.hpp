@@ -208,6 +208,9 @@ struct Fp30 {
 // (lazy reduction: the two double-width sums are reduced once each), i.e. 6 NL^2 multiply-adds -- the
 // same count as Karatsuba's 3 full products, with outputs that obey the single-product bound (< 1.5p)
 // so the group formulas and their K constants are shared with G1.  Inputs: components < 16p.
+// mul/sqr are out-of-line by default: fully inlined, the G2 bucket kernel is ~300 KB of code and, once
+// the waves of a CU drift apart, instruction fetch (64 KB I-cache) becomes the bottleneck -- measured
+// 129 ms (inlined) vs 83 ms (out-of-line) for the 2^22-point G2 bucket pass (profiles/r01_*).
 template <class P>
 struct Fp2x30 {
     typedef Fp30<P> B;
@@ -243,14 +246,14 @@ struct Fp2x30 {
     G16_HD_NOINLINE static Fp2x30 mul_outlined(const Fp2x30& a, const Fp2x30& b) { return a.mul_impl(b); }
     G16_HD_NOINLINE static Fp2x30 sqr_outlined(const Fp2x30& a) { return a.sqr_impl(); }
     G16_HD Fp2x30 mul(const Fp2x30& o) const {
-#ifndef G16_FP2X30_OUTLINE
+#ifdef G16_FP2X30_INLINE
         return mul_impl(o);
 #else
         return mul_outlined(*this, o);
 #endif
     }
     G16_HD Fp2x30 sqr() const {
-#ifndef G16_FP2X30_OUTLINE
+#ifdef G16_FP2X30_INLINE
         return sqr_impl();
 #else
         return sqr_outlined(*this);

@@ -129,12 +129,21 @@ struct ScalarSort {
 };
 template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipStream_t st, ScalarSort* out);
 
-// Pippenger over one base array using a ScalarSort.  Sorted index p addresses bases[p + shift]
-// when 0 <= p + shift < base_count (other entries are skipped: lets l_query reuse the sort made
-// for a/b).  Writes the W per-window sums (XYZZ) to host memory `window_sums` after a stream sync
-// is issued by the caller; d_window_sums is arena memory.
-template <class F> int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena,
-                                      hipStream_t st, XYZZ<F>** d_window_sums, EventTimer* bucket_timer);
+// Pippenger over one base array using a ScalarSort, in two stream-separable halves:
+//   msm_bucket_pass  the throughput-bound bucket accumulation.  Sorted index p addresses bases[p + shift] when
+//                    0 <= p + shift < base_count (other entries are skipped: lets l_query reuse the sort made for a/b)
+//   msm_reduce       heavy-bucket combine, bucket reduction, window reduction (latency-bound, few waves): meant to
+//                    run on a second stream underneath the next MSM's bucket pass.  Leaves W window sums (standard
+//                    Montgomery form, XYZZ) in buf.window_sums.
+template <class F>
+struct MsmBuffers {
+    XYZZ<F>* partials = nullptr;
+    XYZZ<F>* chunk_out = nullptr;
+    XYZZ<F>* window_sums = nullptr;
+};
+template <class F> int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena,
+                                       hipStream_t st, MsmBuffers<F>* out, EventTimer* bucket_timer);
+template <class F> int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st);
 // MSM bases are kept on the device in the bucket kernel's own Montgomery radix (x*R' with R' = 2^(30 NL), canonical,
 // packed in the usual words): converted in place, once, after upload (F = Fq for G1, Fq2 for G2).
 template <class F> int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st);

@@ -473,24 +473,32 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
 }
 
 template <class F>
-int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena, hipStream_t st,
-                   XYZZ<F>** d_window_sums, EventTimer* bucket_timer) {
+int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena, hipStream_t st,
+                    MsmBuffers<F>* out, EventTimer* bucket_timer) {
     typedef typename Lazy30<F>::type F30;
     const MsmPlan& plan = ss.plan;
     const uint32_t M = plan.B * (uint32_t)plan.W;
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
-    XYZZ<F>*partials = nullptr, *chunk_out = nullptr, *wsum = nullptr;
-    G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
-    G16_TRY(arena.alloc_n((size_t)cpw * plan.W, &chunk_out));
-    G16_TRY(arena.alloc_n((size_t)plan.W, &wsum));
+    G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &out->partials));
+    G16_TRY(arena.alloc_n((size_t)cpw * plan.W, &out->chunk_out));
+    G16_TRY(arena.alloc_n((size_t)plan.W, &out->window_sums));
     if (bucket_timer) G16_TRY(bucket_timer->start(st));
     if (ss.max_tasks) {
         hipLaunchKernelGGL((bucket_accumulate30_kernel<F30>), dim3((ss.max_tasks + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, st,
-                           d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), partials);
+                           d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), out->partials);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));
+    return G16_OK;
+}
+
+template <class F>
+int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
+    typedef typename Lazy30<F>::type F30;
+    const MsmPlan& plan = ss.plan;
+    const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
+    const uint32_t cpw = plan.B / G;
     static bool attr_set = false;
     const size_t lds_heavy = sizeof(XYZZ<F>) * HEAVY_THREADS, lds_win = sizeof(XYZZ<F>) * RED_THREADS;
     if (!attr_set) {
@@ -498,14 +506,13 @@ int msm_accumulate(const Affine<F>* d_bases, int64_t shift, uint64_t base_count,
                                         (int)lds_heavy));
         attr_set = true;
     }
-    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, partials, ss.task_off, ss.heavy);
+    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, buf.partials, ss.task_off, ss.heavy);
     G16_LAUNCH_CHECK();
-    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, partials,
-                       ss.task_off, plan.B, plan.W, G, chunk_out);
+    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, buf.partials,
+                       ss.task_off, plan.B, plan.W, G, buf.chunk_out);
     G16_LAUNCH_CHECK();
-    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.W), dim3(RED_THREADS), lds_win, st, chunk_out, cpw, wsum);
+    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.W), dim3(RED_THREADS), lds_win, st, buf.chunk_out, cpw, buf.window_sums);
     G16_LAUNCH_CHECK();
-    *d_window_sums = wsum;
     return G16_OK;
 }
 
@@ -531,10 +538,12 @@ XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
     template int convert_bases<typename C::Fq>(Affine<typename C::Fq>*, uint64_t, hipStream_t);                             \
     template int convert_bases<typename C::Fq2>(Affine<typename C::Fq2>*, uint64_t, hipStream_t);                           \
     template int sort_scalars<C>(const typename C::Fr*, uint64_t, Arena&, hipStream_t, ScalarSort*);                        \
-    template int msm_accumulate<typename C::Fq>(const Affine<typename C::Fq>*, int64_t, uint64_t, const ScalarSort&, Arena&, \
-                                                hipStream_t, XYZZ<typename C::Fq>**, EventTimer*);                           \
-    template int msm_accumulate<typename C::Fq2>(const Affine<typename C::Fq2>*, int64_t, uint64_t, const ScalarSort&,      \
-                                                 Arena&, hipStream_t, XYZZ<typename C::Fq2>**, EventTimer*);                 \
+    template int msm_bucket_pass<typename C::Fq>(const Affine<typename C::Fq>*, int64_t, uint64_t, const ScalarSort&, Arena&, \
+                                                 hipStream_t, MsmBuffers<typename C::Fq>*, EventTimer*);                      \
+    template int msm_bucket_pass<typename C::Fq2>(const Affine<typename C::Fq2>*, int64_t, uint64_t, const ScalarSort&,     \
+                                                  Arena&, hipStream_t, MsmBuffers<typename C::Fq2>*, EventTimer*);            \
+    template int msm_reduce<typename C::Fq>(const MsmBuffers<typename C::Fq>&, const ScalarSort&, hipStream_t);             \
+    template int msm_reduce<typename C::Fq2>(const MsmBuffers<typename C::Fq2>&, const ScalarSort&, hipStream_t);           \
     template XYZZ<typename C::Fq> fold_windows<typename C::Fq>(const XYZZ<typename C::Fq>*, const MsmPlan&);               \
     template XYZZ<typename C::Fq2> fold_windows<typename C::Fq2>(const XYZZ<typename C::Fq2>*, const MsmPlan&);
 
