@@ -13,7 +13,8 @@ Reference interface mirrored (paths relative to /root/reference):
   SynthesisError.PolynomialDegreeTooLarge            src/r1cs_to_qap.rs:178-179
 """
 from .binding import (G16Error, Lib, PolynomialDegreeTooLarge, SynthesisError, lib, FQ_LIMBS, CURVE_ID)  # noqa: F401
-from .groth16 import ConstraintMatrices, Groth16, LibsnarkReduction, Proof, ProvingKey, ShardedProver  # noqa: F401
+from .groth16 import (ConstraintMatrices, Groth16, LibsnarkReduction, Proof, ProvingKey, ShardedProver, finalize_host,  # noqa: F401
+                      shard_ranges)
 
 __all__ = [
     "Groth16", "LibsnarkReduction", "ConstraintMatrices", "ProvingKey", "Proof", "ShardedProver", "G16Error", "SynthesisError",

@@ -70,7 +70,7 @@ class TimingsC(C.Structure):
 
 EXPORTS = [
     "g16_ctx_create", "g16_ctx_destroy", "g16_ctx_stream", "g16_pk_load", "g16_pk_free", "g16_circuit_load", "g16_circuit_free",
-    "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_get_timings", "g16_witness_map",
+    "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_finalize_host", "g16_get_timings", "g16_witness_map",
     "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
     "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version",
 ]
@@ -117,6 +117,7 @@ class Lib:
         c.g16_prove_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
                                         C.POINTER(PartialC)]
         c.g16_prove_finalize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PartialC), C.c_int, u64p, u64p, C.POINTER(ProofC)]
+        c.g16_finalize_host.argtypes = [C.c_int, C.POINTER(PkViewC), C.POINTER(PartialC), C.c_int, u64p, u64p, C.POINTER(ProofC)]
         c.g16_get_timings.argtypes = [C.c_void_p, C.POINTER(TimingsC)]
         c.g16_witness_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, u64p]
         c.g16_msm_g1.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, u64p]

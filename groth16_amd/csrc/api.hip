@@ -366,14 +366,16 @@ struct Impl {
     }
 
     // prover.rs:76-131 glue over the summed MSM results
-    static int prove_finalize(g16_ctx* ctx, const g16_pk* pkh, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
-                              g16_proof* out) {
-        const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
+    struct FixedPoints {
+        G1A alpha_g1, beta_g1, delta_g1, a_query0, b_g1_query0;
+        G2A beta_g2, delta_g2, b_g2_query0;
+    };
+    static int finalize_core(const FixedPoints& pk, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
+                             g16_proof* out) {
         if (n_parts < 1) return G16_ERR_BAD_ARG;
-        const double t0 = now_ms();
         G1X h_acc = G1X::identity(), l_acc = G1X::identity(), a_msm = G1X::identity(), b1_msm = G1X::identity();
         G2X b2_msm = G2X::identity();
-        for (int i = 0; i < n_parts; ++i) {
+        for (int i = 0; i < n_parts; ++i) {  // the N-way EC fold of the all-gathered shard records
             h_acc.add(load_xyzz<G1X>(parts[i].h));
             l_acc.add(load_xyzz<G1X>(parts[i].l));
             a_msm.add(load_xyzz<G1X>(parts[i].a));
@@ -386,25 +388,25 @@ struct Impl {
         s.to_canonical(sk);
         (r * s).to_canonical(rsk);
         const int nb = Fr::Params::BITS;
-        const G1X delta1 = G1X::from_affine(pk->delta_g1);
+        const G1X delta1 = G1X::from_affine(pk.delta_g1);
         const G1X r_s_delta_g1 = delta1.mul_bits(rsk, nb);                      // :76
         // g_a = r*delta_g1 + a_query[0] + msm + alpha_g1   (calculate_coeff, :90-92, :252-270)
         G1X g_a = delta1.mul_bits(rk, nb);
-        g_a.add_affine(pk->a_query0);
+        g_a.add_affine(pk.a_query0);
         g_a.add(a_msm);
-        g_a.add_affine(pk->alpha_g1);
+        g_a.add_affine(pk.alpha_g1);
         const G1X s_g_a = g_a.mul_bits(sk, nb);                                 // :94
         G1X g1_b = G1X::identity();
         if (!r.is_zero()) {                                                    // :98-108
             g1_b = delta1.mul_bits(sk, nb);
-            g1_b.add_affine(pk->b_g1_query0);
+            g1_b.add_affine(pk.b_g1_query0);
             g1_b.add(b1_msm);
-            g1_b.add_affine(pk->beta_g1);
+            g1_b.add_affine(pk.beta_g1);
         }
-        G2X g2_b = G2X::from_affine(pk->delta_g2).mul_bits(sk, nb);             // :112-113
-        g2_b.add_affine(pk->b_g2_query0);
+        G2X g2_b = G2X::from_affine(pk.delta_g2).mul_bits(sk, nb);             // :112-113
+        g2_b.add_affine(pk.b_g2_query0);
         g2_b.add(b2_msm);
-        g2_b.add_affine(pk->beta_g2);
+        g2_b.add_affine(pk.beta_g2);
         const G1X r_g1_b = g1_b.mul_bits(rk, nb);                               // :114
         G1X g_c = s_g_a;                                                        // :119-124
         g_c.add(r_g1_b);
@@ -418,10 +420,29 @@ struct Impl {
         memcpy(out->a, &pa, sizeof(pa));
         memcpy(out->b, &pb, sizeof(pb));
         memcpy(out->c, &pc, sizeof(pc));
+        return G16_OK;
+    }
+    static int prove_finalize(g16_ctx* ctx, const g16_pk* pkh, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
+                              g16_proof* out) {
+        const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
+        const double t0 = now_ms();
+        const FixedPoints fp = {pk->alpha_g1, pk->beta_g1, pk->delta_g1, pk->a_query0, pk->b_g1_query0, pk->beta_g2, pk->delta_g2,
+                                pk->b_g2_query0};
+        G16_TRY(finalize_core(fp, parts, n_parts, r_, s_, out));
         const double dt = now_ms() - t0;
         ctx->tm.finish_ms += dt;
         ctx->tm.total_ms += dt;
         return G16_OK;
+    }
+    static int finalize_host(const g16_pk_view* v, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
+                             g16_proof* out) {
+        if (!v->alpha_g1 || !v->beta_g1 || !v->delta_g1 || !v->beta_g2 || !v->delta_g2 || !v->a_query0 || !v->b_g1_query0 ||
+            !v->b_g2_query0)
+            return G16_ERR_BAD_ARG;
+        const FixedPoints fp = {load_pod<G1A>(v->alpha_g1), load_pod<G1A>(v->beta_g1), load_pod<G1A>(v->delta_g1), load_pod<G1A>(v->a_query0),
+                                load_pod<G1A>(v->b_g1_query0), load_pod<G2A>(v->beta_g2), load_pod<G2A>(v->delta_g2),
+                                load_pod<G2A>(v->b_g2_query0)};
+        return finalize_core(fp, parts, n_parts, r_, s_, out);
     }
 
     // ---------------------------------------------------------------------------------------
@@ -879,6 +900,12 @@ int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts,
     if (!ctx || !pk || !parts || !r || !s || !out) return G16_ERR_BAD_ARG;
     if (pk->curve != ctx->curve) return G16_ERR_BAD_ARG;
     G16_DISPATCH(ctx->curve, I::prove_finalize(ctx, pk, parts, n_parts, r, s, out));
+}
+
+int g16_finalize_host(int curve, const g16_pk_view* fixed, const g16_partial* parts, int n_parts, const uint64_t r[4], const uint64_t s[4],
+                      g16_proof* out) {
+    if (!fixed || !parts || !r || !s || !out) return G16_ERR_BAD_ARG;
+    G16_DISPATCH(curve, I::finalize_host(fixed, parts, n_parts, r, s, out));
 }
 
 int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,

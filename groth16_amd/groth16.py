@@ -84,6 +84,17 @@ class Proof:
         return np.concatenate([self.a, self.b, self.c])
 
 
+def shard_ranges(m: int, w: int, h_len: int, num_inputs: int, idx: int, cnt: int):
+    """Contiguous shard `idx` of `cnt` of the five MSM base arrays.  a / b_g1 / b_g2 (index space query[1..], length m)
+    are cut identically; l (length w, index j <-> a-index j + num_inputs - 1) is cut at the matching places so that
+    the library can reuse the witness bucket sort for it; h (length h_len) is cut evenly."""
+    a_lo, a_hi = m * idx // cnt, m * (idx + 1) // cnt
+    l_lo = min(w, max(0, a_lo - (num_inputs - 1)))
+    l_hi = min(w, max(0, a_hi - (num_inputs - 1)))
+    h_lo, h_hi = h_len * idx // cnt, h_len * (idx + 1) // cnt
+    return dict(a=(a_lo, a_hi), l=(l_lo, l_hi), h=(h_lo, h_hi))
+
+
 class _Ctx:
     def __init__(self, curve: str, device: int):
         self.lib = lib()
@@ -105,24 +116,14 @@ class _DevicePk:
         self.handle = C.c_void_p()
         self._keep = []
         idx, cnt = shard
-        m = len(pk.a_query) - 1
-
-        def rng(n):
-            lo = n * idx // cnt
-            hi = n * (idx + 1) // cnt
-            return lo, hi
+        rg = shard_ranges(len(pk.a_query) - 1, len(pk.l_query), len(pk.h_query), num_inputs, idx, cnt)
+        (a_lo, a_hi), (l_lo, l_hi), (h_lo, h_hi) = rg["a"], rg["l"], rg["h"]
 
         def q(arr: np.ndarray, skip: int, lo: int, hi: int) -> QueryC:
             sl = _c(arr[skip + lo: skip + hi])
             self._keep.append(sl)
             return QueryC(sl.ctypes.data if len(sl) else None, hi - lo, lo)
 
-        a_lo, a_hi = rng(m)
-        # keep l aligned with a so that the library can reuse one bucket sort (l index j <-> a index j + num_inputs - 1)
-        w = len(pk.l_query)
-        l_lo = min(w, max(0, a_lo - (num_inputs - 1))) if idx else 0
-        l_hi = min(w, max(0, a_hi - (num_inputs - 1))) if idx < cnt - 1 else w
-        h_lo, h_hi = rng(len(pk.h_query))
         keep = [_c(x).reshape(-1) for x in (pk.alpha_g1, pk.beta_g1, pk.delta_g1, pk.beta_g2, pk.delta_g2, pk.a_query[0],
                                             pk.b_g1_query[0], pk.b_g2_query[0])]
         self._keep += keep
@@ -305,6 +306,25 @@ class Groth16:
         lb.check(lb.c.g16_prove_finalize(self._ctx.handle, dpk.handle, arr, len(parts), ptr64(_c(r)), ptr64(_c(s)), C.byref(out)))
         return Proof(np.array(out.a[: 2 * L], dtype=np.uint64), np.array(out.b[: 4 * L], dtype=np.uint64),
                      np.array(out.c[: 2 * L], dtype=np.uint64))
+
+
+def fixed_points_view(pk: "ProvingKey"):
+    """g16_pk_view with only the eight fixed points filled (what g16_finalize_host reads); returns (view, keepalive)"""
+    keep = [_c(x).reshape(-1) for x in (pk.alpha_g1, pk.beta_g1, pk.delta_g1, pk.beta_g2, pk.delta_g2, pk.a_query[0], pk.b_g1_query[0],
+                                        pk.b_g2_query[0])]
+    empty = QueryC(None, 0, 0)
+    return PkViewC(*[ptr64(k) for k in keep], empty, empty, empty, empty, empty, 0), keep
+
+
+def finalize_host(curve: str, pk: "ProvingKey", parts: Sequence[bytes], r: np.ndarray, s: np.ndarray) -> "Proof":
+    """g16_finalize_host: N-way EC fold of shard records + the prover.rs:76-131 glue, no GPU needed"""
+    L = FQ_LIMBS[curve]
+    view, keep = fixed_points_view(pk)
+    arr = (PartialC * len(parts))(*[PartialC.from_buffer_copy(p) for p in parts])
+    out = ProofC()
+    lb = lib()
+    lb.check(lb.c.g16_finalize_host(CURVE_ID[curve], C.byref(view), arr, len(parts), ptr64(_c(r)), ptr64(_c(s)), C.byref(out)))
+    return Proof(np.array(out.a[: 2 * L], dtype=np.uint64), np.array(out.b[: 4 * L], dtype=np.uint64), np.array(out.c[: 2 * L], dtype=np.uint64))
 
 
 class ShardedProver:

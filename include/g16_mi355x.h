@@ -140,6 +140,11 @@ int g16_prove_partial(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit
 int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts, int n_parts, const uint64_t r[4],
                        const uint64_t s[4], g16_proof* out);
 
+/* the same fold + glue without a GPU context: only the eight fixed points of `fixed` are read.  Lets a host
+ * process that merely aggregates shard records (or the CPU multi-rank tests) finish a proof. */
+int g16_finalize_host(int curve, const g16_pk_view* fixed, const g16_partial* parts, int n_parts, const uint64_t r[4],
+                      const uint64_t s[4], g16_proof* out);
+
 int g16_get_timings(g16_ctx* ctx, g16_timings* out);
 
 /* ---- unit-level entry points (parity tests, micro-benchmarks) ---- */
