@@ -753,6 +753,22 @@ struct Impl {
             if (a.is_zero_exact() != x.is_zero()) return 25;
             if (!a.template sub<8>(a).is_zero_exact()) return 26;
         }
+        // ---- the bucket kernel's Karatsuba Fq2 (register-passed products, settled accumulator)
+        typedef Fp2k30<typename Fq::Params> FK;
+        for (int it = 0; it < iters / 4 + 4; ++it) {
+            Fq2 x = {rand_fq(st), rand_fq(st)}, y = {rand_fq(st), rand_fq(st)};
+            if (it == 0) x = Fq2::zero();
+            if (it == 1) { x = {Fq::zero() - Fq::one(), Fq::zero() - Fq::one()}; y = x; }
+            const FK a = {to30(x.c0), to30(x.c1)}, b = {to30(y.c0), to30(y.c1)};
+            if (!(a.mul(b).to_std() == x * y)) return 30;
+            if (!(a.sqr().to_std() == x.sqr())) return 31;
+            const FK big1 = a.add(b).add(a).template sub<8>(b), big2 = b.template sub<8>(a).add(b);  // 2a (<12p), 2b - a (<11p)
+            if (!(big1.mul(big2).to_std() == (x + x) * (y + y - x))) return 32;
+            if (!(big1.sqr().to_std() == (x + x).sqr())) return 33;
+            const FK wide = big1.add(big1).template sub<16>(b);      // 4a - b, bound < 30p
+            if (!(wide.settle().to_std() == (x + x + x + x - y))) return 34;
+            if (!(wide.settle().mul(b).to_std() == (x + x + x + x - y) * y)) return 35;
+        }
         {
             const G2A gen2 = C::g2_generator();
             std::vector<G2A> pts2;
@@ -774,6 +790,20 @@ struct Impl {
                     acc.add_affine(px, py);
                     ref.add_affine(seq[i]);
                     if (!(acc.to_std().to_affine() == ref.to_affine())) return 1000 + round * 100 + (int)i;
+                }
+                {   // the same sequence through the Karatsuba accumulator used by the G2 bucket kernel
+                    Acc30<FK> ak = Acc30<FK>::identity();
+                    G2X rk = G2X::identity();
+                    for (size_t i = 0; i < seq.size(); ++i) {
+                        const FK px = {to30(seq[i].x.c0), to30(seq[i].x.c1)};
+                        FK py = {to30(seq[i].y.c0), to30(seq[i].y.c1)};
+                        G2A q = seq[i];
+                        if (i & 1) { py = py.neg2(); q = q.neg(); }
+                        ak.add_affine(px, py);
+                        rk.add_affine(q);
+                        if (!(ak.to_std().to_affine() == rk.to_affine())) return 3000 + round * 100 + (int)i;
+                        if (!(Acc30<FK>::from_packed(ak.to_packed()).to_std().to_affine() == rk.to_affine())) return 3500 + round * 100 + (int)i;
+                    }
                 }
                 // full add / dbl / small multiple on G2
                 Acc30<F230> other = Acc30<F230>::from_packed(acc.to_packed());

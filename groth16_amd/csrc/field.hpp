@@ -113,6 +113,52 @@ struct alignas(16) Fp {
     G16_HD_NOINLINE static Fp mul_outlined(const Fp& a, const Fp& b) { return a.mul_inlined(b); }
 #endif
     G16_HD Fp mul_inlined(const Fp& o) const {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+        // host: the same Montgomery product on 64-bit limbs (R = 2^(32N) = 2^(64 N/2) is the same radix),
+        // ~3x faster on x86 than the 32-bit formulation that suits the GPU
+        {
+            constexpr int M = N / 2;
+            typedef unsigned __int128 u128;
+            uint64_t a[M], b[M], p[M], t[M + 2];
+            for (int i = 0; i < M; ++i) {
+                a[i] = (uint64_t)v[2 * i] | ((uint64_t)v[2 * i + 1] << 32);
+                b[i] = (uint64_t)o.v[2 * i] | ((uint64_t)o.v[2 * i + 1] << 32);
+                p[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
+            }
+            // -p^-1 mod 2^64 from the 32-bit constant by one Newton step
+            const uint64_t inv32 = P::INV;               // -p^-1 mod 2^32
+            uint64_t x = (uint64_t)0 - inv32;            // p^-1 mod 2^32 (as a 64-bit value, correct in the low 32 bits)
+            x *= 2 - p[0] * x;                           // now correct mod 2^64
+            const uint64_t inv64 = (uint64_t)0 - x;
+            for (int i = 0; i < M + 2; ++i) t[i] = 0;
+            for (int i = 0; i < M; ++i) {
+                uint64_t carry = 0;
+                for (int j = 0; j < M; ++j) {
+                    const u128 y = (u128)a[j] * b[i] + t[j] + carry;
+                    t[j] = (uint64_t)y;
+                    carry = (uint64_t)(y >> 64);
+                }
+                u128 sacc = (u128)t[M] + carry;
+                t[M] = (uint64_t)sacc;
+                t[M + 1] = (uint64_t)(sacc >> 64);
+                const uint64_t mq = t[0] * inv64;
+                u128 y = (u128)mq * p[0] + t[0];
+                carry = (uint64_t)(y >> 64);
+                for (int j = 1; j < M; ++j) {
+                    y = (u128)mq * p[j] + t[j] + carry;
+                    t[j - 1] = (uint64_t)y;
+                    carry = (uint64_t)(y >> 64);
+                }
+                sacc = (u128)t[M] + carry;
+                t[M - 1] = (uint64_t)sacc;
+                t[M] = t[M + 1] + (uint64_t)(sacc >> 64);
+            }
+            Fp r;
+            for (int i = 0; i < M; ++i) { r.v[2 * i] = (uint32_t)t[i]; r.v[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+            reduce_once(r.v);
+            return r;
+        }
+#endif
         uint32_t t[N];
         G16_UNROLL for (int i = 0; i < N; ++i) t[i] = 0;
         G16_UNROLL for (int i = 0; i < N; ++i) {

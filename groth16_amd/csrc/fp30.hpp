@@ -108,6 +108,16 @@ struct Fp30 {
             G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)a.l[i] * b.l[j];
         }
     }
+    // T = a*a with the symmetric products taken once against the doubled operand: NL(NL+1)/2 multiply-adds.
+    // A column holds <= NL/2 doubled products (< 2^61) and one square (< 2^60): <= 6.5 * 2^61 < 2^64 for NL = 13.
+    G16_HD static void wide_sqr(uint64_t* T, const Fp30& a) {
+        G16_UNROLL for (int c = 0; c < 2 * NL; ++c) T[c] = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            T[2 * i] += (uint64_t)a.l[i] * a.l[i];
+            const uint32_t a2 = a.l[i] << 1;
+            G16_UNROLL for (int j = i + 1; j < NL; ++j) T[i + j] += (uint64_t)a2 * a.l[j];
+        }
+    }
     // T += a*b; T must be normalised (columns < 2^30 + small) on entry
     G16_HD static void wide_mul_add(uint64_t* T, const Fp30& a, const Fp30& b) {
         G16_UNROLL for (int i = 0; i < NL; ++i) {
@@ -145,7 +155,16 @@ struct Fp30 {
         return wide_redc(T);
     }
     G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
-    G16_HD Fp30 sqr() const { return mul(*this); }
+    G16_HD Fp30 sqr() const {
+#if defined(G16_FP30_OUTLINE) || defined(G16_FP30_NO_SQR)
+        return mul(*this);
+#else
+        uint64_t T[2 * NL];
+        wide_sqr(T, *this);
+        wide_normalize(T);
+        return wide_redc(T);
+#endif
+    }
 
     // exact: is the value (any bound < 16p, normalised) congruent to 0 mod p?
     // Fast filter on the low limb: v = k p with k < 16 forces (v0 * p^-1 mod 2^30) = k < 16.
@@ -164,6 +183,28 @@ struct Fp30 {
         G16_UNROLL for (int i = 0; i < NL; ++i) diff |= kp.l[i] ^ l[i];
         return diff == 0;
     }
+    // v >= c ? v - c : v   for normalised v and a normalised constant c (limbs30 of k*p)
+    template <int K>
+    G16_HD Fp30 cond_sub() const {
+        Fp30 d;
+        int32_t br = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            const uint32_t c = K == 2 ? P::np2(i) : K == 4 ? P::np4(i) : K == 8 ? P::np8(i) : P::np16(i);
+            const int32_t v = (int32_t)l[i] - (int32_t)c + br;
+            if (i == NL - 1) { d.l[i] = (uint32_t)v; br = v >> 31; }
+            else { d.l[i] = (uint32_t)v & MASK; br = v >> 30; }
+        }
+        Fp30 r;
+        const bool lt = br < 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = lt ? l[i] : d.l[i];
+        return r;
+    }
+    // value < 32p  ->  value < 2p  (same residue)
+    G16_HD Fp30 weak_reduce32() const { return cond_sub<16>().template cond_sub<8>().template cond_sub<4>().template cond_sub<2>(); }
+    // accumulator trait constants (see Acc30): bounds of this field's product outputs are < 1.5p
+    static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
+    G16_HD Fp30 settle() const { return *this; }
+
     // exact reduction to [0, p) of a normalised value < 2p (e.g. a product output)
     G16_HD Fp30 canonical_lt2p() const {
         Fp30 d;
@@ -263,10 +304,58 @@ struct Fp2x30 {
     G16_HD bool is_zero_exact() const { return c0.is_zero_exact() && c1.is_zero_exact(); }
     G16_HD Std to_std() const { return {c0.to_std(), c1.to_std()}; }
     G16_HD Std to_packed() const { return {c0.to_packed(), c1.to_packed()}; }
+    static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
+    G16_HD Fp2x30 settle() const { return *this; }
 };
 
-// Lazy extended-Jacobian accumulator, F = Fp30<P> (G1) or Fp2x30<P> (G2).  Invariants between calls
-// (per base-field component): x < 7.5p, y < 3.5p, zz < 1.8p, zzz < 1.5p; identity kept as a flag.
+// Fq2 for the G2 BUCKET kernel: Karatsuba over three base-field products that are passed in registers
+// (Fp30::mul_outlined by value) or inlined.  Unlike Fp2x30 no operand ever lives in scratch memory: the
+// out-of-line Fp2x30 product moved ~250 GB of scratch traffic per 2^22-point launch (rocprofv3 FETCH_SIZE +
+// WRITE_SIZE, profiles/r01_pmc_*).  Price: product outputs are only < 6p (c0 = v0 - v1 + 2p, c1 = v2 - v0 - v1 + 4p),
+// so the accumulator subtracts with larger K and "settles" X3 / Y3 with a weak reduction (4 conditional
+// subtractions, ~3 % of a mixed addition).
+template <class P>
+struct Fp2k30 {
+    typedef Fp30<P> B;
+    typedef Fp2<P> Std;
+    B c0, c1;
+    G16_HD static Fp2k30 zero() { return {B::zero(), B::zero()}; }
+    G16_HD static Fp2k30 one() { return {B::one(), B::zero()}; }
+    G16_HD static Fp2k30 from_packed(const Std& x) { return {B::unpack(x.c0.v), B::unpack(x.c1.v)}; }
+    G16_HD Fp2k30 add(const Fp2k30& o) const { return {c0.add(o.c0), c1.add(o.c1)}; }
+    G16_HD Fp2k30 dbl() const { return {c0.dbl(), c1.dbl()}; }
+    template <int K>
+    G16_HD Fp2k30 sub(const Fp2k30& o) const { return {c0.template sub<K>(o.c0), c1.template sub<K>(o.c1)}; }
+    G16_HD Fp2k30 neg2() const { return {c0.neg2(), c1.neg2()}; }
+    G16_HD static B bmul(const B& a, const B& b) {
+#ifdef G16_FP2K_INLINE
+        return a.mul_impl(b);
+#else
+        return B::mul_outlined(a, b);
+#endif
+    }
+    // inputs: components < 16p
+    G16_HD Fp2k30 mul(const Fp2k30& o) const {
+        const B v0 = bmul(c0, o.c0), v1 = bmul(c1, o.c1);       // < 1.5p
+        const B v2 = bmul(c0.add(c1), o.c0.add(o.c1));          // operands < 32p
+        return {v0.template sub<2>(v1), v2.template sub<4>(v0.add(v1))};   // < 3.5p, < 5.5p
+    }
+    G16_HD Fp2k30 sqr() const {                                 // both components < 2p
+        return {bmul(c0.add(c1), c0.template sub<16>(c1)), bmul(c0.dbl(), c1)};
+    }
+    G16_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
+    G16_HD bool is_zero_exact() const { return c0.is_zero_exact() && c1.is_zero_exact(); }
+    G16_HD Std to_std() const { return {c0.to_std(), c1.to_std()}; }
+    G16_HD Std to_packed() const { return {c0.to_packed(), c1.to_packed()}; }
+    // product outputs < 6p -> subtract them with K = 8 (16 when doubled); x, y are settled below 2p
+    static constexpr int KM = 8, K2M = 16, KX = 2, KY = 2;
+    G16_HD Fp2k30 settle() const { return {c0.weak_reduce32(), c1.weak_reduce32()}; }
+};
+
+// Lazy extended-Jacobian accumulator, F = Fp30<P> (G1), Fp2x30<P> or Fp2k30<P> (G2).  Invariants between
+// calls (per base-field component), "tight" fields (product outputs < 1.5p): x < 7.5p, y < 3.5p, zz, zzz < 1.8p;
+// Karatsuba field (product outputs < 6p): x, y < 2p (settled), zz, zzz < 6p.  The K of every subtraction is the
+// field's trait constant: KM for a product output, K2M for a doubled one, KX / KY for x / y; identity kept as a flag.
 template <class F>
 struct Acc30 {
     typedef typename F::Std StdF;
@@ -283,13 +372,13 @@ struct Acc30 {
     G16_HD void set_double(const F& px, const F& py) {
         const F U = py.dbl();                     // < 4p
         if (U.is_zero_exact()) { inf = true; return; }
-        const F V = U.sqr();                      // < 1.5p
+        const F V = U.sqr();
         const F W = U.mul(V);
         const F S = px.mul(V);
         const F X2 = px.sqr();
-        const F M = X2.dbl().add(X2);             // < 4.5p
-        const F X3 = M.sqr().template sub<4>(S.dbl());          // < 5.5p
-        const F Y3 = M.mul(S.template sub<8>(X3)).template sub<2>(W.mul(py));  // < 3.5p
+        const F M = X2.dbl().add(X2);             // < 3 * (square bound)
+        const F X3 = M.sqr().template sub<F::K2M>(S.dbl()).settle();
+        const F Y3 = M.mul(S.template sub<F::KX>(X3)).template sub<F::KM>(W.mul(py)).settle();
         x = X3; y = Y3; zz = V; zzz = W;
         inf = false;
     }
@@ -300,10 +389,10 @@ struct Acc30 {
             inf = false;
             return;
         }
-        const F U2 = px.mul(zz);                  // < 1.5p
+        const F U2 = px.mul(zz);
         const F S2 = py.mul(zzz);
-        const F Pd = U2.template sub<8>(x);       // < 9.5p
-        const F R = S2.template sub<4>(y);        // < 5.5p
+        const F Pd = U2.template sub<F::KX>(x);
+        const F R = S2.template sub<F::KY>(y);
         if (Pd.maybe_zero()) {
             if (Pd.is_zero_exact()) {
                 if (R.is_zero_exact()) set_double(px, py);
@@ -311,11 +400,11 @@ struct Acc30 {
                 return;
             }
         }
-        const F PP = Pd.sqr();                    // < 1.8p (Fq2 squaring of a 9.5p operand)
-        const F PPP = Pd.mul(PP);                 // < 1.5p
+        const F PP = Pd.sqr();
+        const F PPP = Pd.mul(PP);
         const F Q = x.mul(PP);
-        const F X3 = R.sqr().template sub<2>(PPP).template sub<4>(Q.dbl());        // < 7.5p
-        const F Y3 = R.mul(Q.template sub<8>(X3)).template sub<2>(y.mul(PPP));     // < 3.5p
+        const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
+        const F Y3 = R.mul(Q.template sub<F::KX>(X3)).template sub<F::KM>(y.mul(PPP)).settle();
         x = X3;
         y = Y3;
         zz = zz.mul(PP);
@@ -324,15 +413,15 @@ struct Acc30 {
     // dbl-2008-s-1
     G16_HD void dbl() {
         if (inf) return;
-        const F U = y.dbl();                      // < 7p
+        const F U = y.dbl();
         if (U.is_zero_exact()) { inf = true; return; }
         const F V = U.sqr();
         const F W = U.mul(V);
         const F S = x.mul(V);
         const F X2 = x.sqr();
-        const F M = X2.dbl().add(X2);             // < 4.5p
-        const F X3 = M.sqr().template sub<4>(S.dbl());                       // < 5.5p
-        const F Y3 = M.mul(S.template sub<8>(X3)).template sub<2>(W.mul(y));  // < 3.5p
+        const F M = X2.dbl().add(X2);
+        const F X3 = M.sqr().template sub<F::K2M>(S.dbl()).settle();
+        const F Y3 = M.mul(S.template sub<F::KX>(X3)).template sub<F::KM>(W.mul(y)).settle();
         x = X3; y = Y3;
         zz = V.mul(zz);
         zzz = W.mul(zzz);
@@ -341,12 +430,12 @@ struct Acc30 {
     G16_HD void add(const Acc30& o) {
         if (o.inf) return;
         if (inf) { *this = o; return; }
-        const F U1 = x.mul(o.zz);                 // all < 1.5p
+        const F U1 = x.mul(o.zz);
         const F U2 = o.x.mul(zz);
         const F S1 = y.mul(o.zzz);
         const F S2 = o.y.mul(zzz);
-        const F Pd = U2.template sub<2>(U1);      // < 3.5p
-        const F R = S2.template sub<2>(S1);
+        const F Pd = U2.template sub<F::KM>(U1);
+        const F R = S2.template sub<F::KM>(S1);
         if (Pd.maybe_zero()) {
             if (Pd.is_zero_exact()) {
                 if (R.is_zero_exact()) dbl();
@@ -357,8 +446,8 @@ struct Acc30 {
         const F PP = Pd.sqr();
         const F PPP = Pd.mul(PP);
         const F Q = U1.mul(PP);
-        const F X3 = R.sqr().template sub<2>(PPP).template sub<4>(Q.dbl());       // < 7.5p
-        const F Y3 = R.mul(Q.template sub<8>(X3)).template sub<2>(S1.mul(PPP));   // < 3.5p
+        const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
+        const F Y3 = R.mul(Q.template sub<F::KX>(X3)).template sub<F::KM>(S1.mul(PPP)).settle();
         x = X3;
         y = Y3;
         zz = zz.mul(o.zz).mul(PP);

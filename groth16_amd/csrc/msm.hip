@@ -37,6 +37,9 @@ namespace g16 {
 
 static constexpr int SORT_THREADS = 1024;
 static constexpr int ACC_THREADS = 128;
+#ifndef G16_ACC_MIN_WAVES
+#define G16_ACC_MIN_WAVES 1
+#endif
 static constexpr int RED_THREADS = 64;
 static constexpr uint32_t REDUCE_G = 16;  // buckets per lane in the bucket reduction
 
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate_kernel(const Af
 // stored in the same R' domain (XYZZ, canonical, packed) and only the W window sums are converted to
 // the standard arkworks radix for the host.
 template <class F30>
-__global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate30_kernel(const Affine<typename F30::Std>* __restrict__ bases,
+__global__ __launch_bounds__(ACC_THREADS, G16_ACC_MIN_WAVES) void bucket_accumulate30_kernel(const Affine<typename F30::Std>* __restrict__ bases,
                                                                           int64_t shift, uint64_t base_count,
                                                                           const uint32_t* __restrict__ sorted,
                                                                           const uint32_t* __restrict__ offsets,
@@ -255,9 +258,16 @@ __global__ void convert_bases30_kernel(Affine<F>* __restrict__ pts, uint64_t n) 
     pts[i] = a;
 }
 
-template <class F> struct Lazy30;
-template <class P> struct Lazy30<Fp<P>> { typedef Fp30<P> type; };
-template <class P> struct Lazy30<Fp2<P>> { typedef Fp2x30<P> type; };
+template <class F> struct Lazy30;   // field used by the reduction kernels (and by the G1 bucket pass)
+template <class P> struct Lazy30<Fp<P>> { typedef Fp30<P> type; typedef Fp30<P> acc_type; };
+template <class P> struct Lazy30<Fp2<P>> {
+    typedef Fp2x30<P> type;
+#ifdef G16_G2_ACC_FP2X30
+    typedef Fp2x30<P> acc_type;
+#else
+    typedef Fp2k30<P> acc_type;   // bucket pass: register-passed Karatsuba, no scratch operands
+#endif
+};
 
 // ---------------------------------------------------------------------------------------------
 // 5b. heavy buckets: a bucket that was split over several tasks (short top window, repeated
@@ -475,7 +485,7 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
 template <class F>
 int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena, hipStream_t st,
                     MsmBuffers<F>* out, EventTimer* bucket_timer) {
-    typedef typename Lazy30<F>::type F30;
+    typedef typename Lazy30<F>::acc_type F30;
     const MsmPlan& plan = ss.plan;
     const uint32_t M = plan.B * (uint32_t)plan.W;
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
