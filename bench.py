@@ -254,7 +254,17 @@ def main():
         alg_bytes = n_pts * (base_bytes + 32)
         avg_ms = float(np.mean(bucket_g1)) if bucket_g1 else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, committed under profiles/);
+        # only valid for the workload they were collected on
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            wl = pt["workload"]
+            if wl["curve"] == args.curve and wl["log2_domain"] == args.log2 and wl["n_gpus"] == world:
+                traffic = pt["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            pass
+        roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         kernel="bucket_accumulate30_kernel (G1 Pippenger bucket pass)", launches_per_step=len(bucket_g1) // args.steps,
                         avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg_bytes,
                         note="integer-VALU bound in practice (10 Fq products per 128 B); see DESIGN.md",

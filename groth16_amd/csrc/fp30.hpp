@@ -204,6 +204,11 @@ struct Fp30 {
     // accumulator trait constants (see Acc30): bounds of this field's product outputs are < 1.5p
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD Fp30 settle() const { return *this; }
+#ifndef G16_ACC_MIN_WAVES
+#define G16_ACC_MIN_WAVES 1
+#endif
+    static constexpr int ACC_MIN_WAVES = G16_ACC_MIN_WAVES;
+    static constexpr bool ACC_PREFETCH = true;
 
     // exact reduction to [0, p) of a normalised value < 2p (e.g. a product output)
     G16_HD Fp30 canonical_lt2p() const {
@@ -306,6 +311,8 @@ struct Fp2x30 {
     G16_HD Std to_packed() const { return {c0.to_packed(), c1.to_packed()}; }
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD Fp2x30 settle() const { return *this; }
+    static constexpr int ACC_MIN_WAVES = 1;
+    static constexpr bool ACC_PREFETCH = false;
 };
 
 // Fq2 for the G2 BUCKET kernel: Karatsuba over three base-field products that are passed in registers
@@ -350,6 +357,11 @@ struct Fp2k30 {
     // product outputs < 6p -> subtract them with K = 8 (16 when doubled); x, y are settled below 2p
     static constexpr int KM = 8, K2M = 16, KX = 2, KY = 2;
     G16_HD Fp2k30 settle() const { return {c0.weak_reduce32(), c1.weak_reduce32()}; }
+#ifndef G16_G2_MIN_WAVES
+#define G16_G2_MIN_WAVES 1
+#endif
+    static constexpr int ACC_MIN_WAVES = G16_G2_MIN_WAVES;
+    static constexpr bool ACC_PREFETCH = false;
 };
 
 // Lazy extended-Jacobian accumulator, F = Fp30<P> (G1), Fp2x30<P> or Fp2k30<P> (G2).  Invariants between

@@ -37,9 +37,6 @@ namespace g16 {
 
 static constexpr int SORT_THREADS = 1024;
 static constexpr int ACC_THREADS = 128;
-#ifndef G16_ACC_MIN_WAVES
-#define G16_ACC_MIN_WAVES 1
-#endif
 static constexpr int RED_THREADS = 64;
 static constexpr uint32_t REDUCE_G = 16;  // buckets per lane in the bucket reduction
 
@@ -213,7 +210,7 @@ __global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate_kernel(const Af
 // stored in the same R' domain (XYZZ, canonical, packed) and only the W window sums are converted to
 // the standard arkworks radix for the host.
 template <class F30>
-__global__ __launch_bounds__(ACC_THREADS, G16_ACC_MIN_WAVES) void bucket_accumulate30_kernel(const Affine<typename F30::Std>* __restrict__ bases,
+__global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(const Affine<typename F30::Std>* __restrict__ bases,
                                                                           int64_t shift, uint64_t base_count,
                                                                           const uint32_t* __restrict__ sorted,
                                                                           const uint32_t* __restrict__ offsets,
@@ -231,16 +228,34 @@ __global__ __launch_bounds__(ACC_THREADS, G16_ACC_MIN_WAVES) void bucket_accumul
     const uint32_t start = offsets[lo] + (k << lmax_log);
     const uint32_t end = min(offsets[lo + 1], start + (1u << lmax_log));
     Acc30<F30> acc = Acc30<F30>::identity();
+    // software pipeline: the (index -> base point) gather of entry e+1 is issued before the ~20k-instruction
+    // addition of entry e, so its two dependent HBM latencies hide under arithmetic
+    typedef Affine<typename F30::Std> A;
+    uint32_t v_next = 0;
+    A p_next = A::identity();
+    bool ok_next = false;
+    auto fetch = [&](uint32_t e) {
+        v_next = sorted[e];
+        const int64_t idx = (int64_t)(v_next & 0x7fffffffu) + shift;
+        ok_next = idx >= 0 && (uint64_t)idx < base_count;
+        if (ok_next) p_next = bases[idx];
+    };
+    if (start < end) fetch(start);
     for (uint32_t e = start; e < end; ++e) {
-        const uint32_t v = sorted[e];
-        const int64_t idx = (int64_t)(v & 0x7fffffffu) + shift;
-        if (idx < 0 || (uint64_t)idx >= base_count) continue;
-        const Affine<typename F30::Std> p = bases[idx];
-        if (p.is_identity()) continue;
+        const uint32_t v = v_next;
+        const A p = p_next;
+        const bool ok = ok_next;
+        if constexpr (F30::ACC_PREFETCH) {
+            if (e + 1 < end) fetch(e + 1);   // G1: -4 % measured; G2 has no registers to spare for it
+        }
+        if (!ok || p.is_identity()) continue;
         const F30 px = F30::from_packed(p.x);
         F30 py = F30::from_packed(p.y);
         if (v >> 31) py = py.neg2();
         acc.add_affine(px, py);
+        if constexpr (!F30::ACC_PREFETCH) {
+            if (e + 1 < end) fetch(e + 1);
+        }
     }
     partials[t] = acc.to_packed();
 }
