@@ -753,6 +753,23 @@ struct Impl {
             if (a.is_zero_exact() != x.is_zero()) return 25;
             if (!a.template sub<8>(a).is_zero_exact()) return 26;
         }
+        // ---- lane-pair Fq2: the pure per-lane kernels against the one-lane Fq2 product
+        typedef Fp2p30<typename Fq::Params> FP;
+        for (int it = 0; it < iters / 4 + 4; ++it) {
+            Fq2 x = {rand_fq(st), rand_fq(st)}, y = {rand_fq(st), rand_fq(st)};
+            if (it == 0) x = Fq2::zero();
+            if (it == 1) { x = {Fq::zero() - Fq::one(), Fq::zero() - Fq::one()}; y = x; }
+            F30 a0 = to30(x.c0), a1 = to30(x.c1), b0 = to30(y.c0), b1 = to30(y.c1);
+            if (it & 1) {   // loosely reduced operands (< 12p)
+                a0 = a0.add(b0).add(a0).template sub<8>(b0); a1 = a1.add(b1).add(a1).template sub<8>(b1);
+                x = x + x;
+            }
+            const Fq2 want_m = x * y, want_s = x.sqr();
+            if (!(FP::pair_mul(false, a0, a1, b0, b1).to_std() == want_m.c0)) return 36;
+            if (!(FP::pair_mul(true, a1, a0, b1, b0).to_std() == want_m.c1)) return 37;
+            if (!(FP::pair_sqr(false, a0, a1).to_std() == want_s.c0)) return 38;
+            if (!(FP::pair_sqr(true, a1, a0).to_std() == want_s.c1)) return 39;
+        }
         // ---- the bucket kernel's Karatsuba Fq2 (register-passed products, settled accumulator)
         typedef Fp2k30<typename Fq::Params> FK;
         for (int it = 0; it < iters / 4 + 4; ++it) {

@@ -209,6 +209,17 @@ struct Fp30 {
 #endif
     static constexpr int ACC_MIN_WAVES = G16_ACC_MIN_WAVES;
     static constexpr bool ACC_PREFETCH = true;
+    // ---- bucket-kernel hooks: one lane per task
+    static constexpr int LANES_PER_TASK = 1;
+    template <class A>
+    G16_HD static bool load_point(const A* bases, int64_t idx, Fp30& px, Fp30& py) {   // false for the identity
+        const A p = bases[idx];
+        if (p.is_identity()) return false;
+        px = from_packed(p.x);
+        py = from_packed(p.y);
+        return true;
+    }
+
 
     // exact reduction to [0, p) of a normalised value < 2p (e.g. a product output)
     G16_HD Fp30 canonical_lt2p() const {
@@ -313,6 +324,17 @@ struct Fp2x30 {
     G16_HD Fp2x30 settle() const { return *this; }
     static constexpr int ACC_MIN_WAVES = 1;
     static constexpr bool ACC_PREFETCH = false;
+    // ---- bucket-kernel hooks: one lane per task
+    static constexpr int LANES_PER_TASK = 1;
+    template <class A>
+    G16_HD static bool load_point(const A* bases, int64_t idx, Fp2x30& px, Fp2x30& py) {   // false for the identity
+        const A p = bases[idx];
+        if (p.is_identity()) return false;
+        px = from_packed(p.x);
+        py = from_packed(p.y);
+        return true;
+    }
+
 };
 
 // Fq2 for the G2 BUCKET kernel: Karatsuba over three base-field products that are passed in registers
@@ -362,6 +384,108 @@ struct Fp2k30 {
 #endif
     static constexpr int ACC_MIN_WAVES = G16_G2_MIN_WAVES;
     static constexpr bool ACC_PREFETCH = false;
+    // ---- bucket-kernel hooks: one lane per task
+    static constexpr int LANES_PER_TASK = 1;
+    template <class A>
+    G16_HD static bool load_point(const A* bases, int64_t idx, Fp2k30& px, Fp2k30& py) {   // false for the identity
+        const A p = bases[idx];
+        if (p.is_identity()) return false;
+        px = from_packed(p.x);
+        py = from_packed(p.y);
+        return true;
+    }
+
+};
+
+// Fq2 for the G2 bucket kernel, LANE-PAIR form: two adjacent lanes (2k, 2k+1) own one bucket; lane parity `hi`
+// selects the component it holds (c0 or c1).  Additions are per-lane; a product fetches the partner's components with one
+// DPP quad-permute per limb and computes ITS output component with the 2-product lazy reduction
+//     lane 0:  c0 = a0 b0 + a1 (16p - b1)        lane 1:  c1 = a0 b1 + a1 b0
+// (507 multiply-adds per lane).  Per-lane state is that of a G1 accumulator, so the kernel keeps two waves per SIMD, needs
+// no calls and no scratch, and its outputs obey the tight (< 1.5p) bound.  Control flow is identical in both lanes of a pair.
+template <class P>
+struct Fp2p30 {
+    typedef Fp30<P> B;
+    typedef Fp2<P> Std;
+    B c;  // this lane's component
+
+    G16_HD static bool lane_hi() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (threadIdx.x & 1u) != 0;
+#else
+        return false;
+#endif
+    }
+    // partner lane's value (lane ^ 1)
+    G16_HD static uint32_t swap32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+#else
+        return v;
+#endif
+    }
+    G16_HD static B swap(const B& x) {
+        B r;
+        G16_UNROLL for (int i = 0; i < B::NL; ++i) r.l[i] = swap32(x.l[i]);
+        return r;
+    }
+    G16_HD static B sel(bool c, const B& a, const B& b) {
+        B r;
+        G16_UNROLL for (int i = 0; i < B::NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+        return r;
+    }
+    // ---- pure per-lane kernels (host-testable): `mine`/`other` are this lane's / the partner's components
+    G16_HD static B pair_mul(bool hi, const B& ma, const B& oa, const B& mb, const B& ob) {
+        const B x1 = sel(hi, oa, ma);                 // lane0: a0      lane1: a0
+        const B x2 = sel(hi, ma, oa);                 // lane0: a1      lane1: a1
+        const B y2 = sel(hi, ob, ob.neg16());         // lane0: 16p-b1  lane1: b0
+        uint64_t T[2 * B::NL];
+        B::wide_mul(T, x1, mb);                       // lane0: a0 b0   lane1: a0 b1
+        B::wide_normalize(T);
+        B::wide_mul_add(T, x2, y2);                   // lane0: + a1(16p-b1)   lane1: + a1 b0
+        B::wide_normalize(T);
+        return B::wide_redc(T);
+    }
+    G16_HD static B pair_sqr(bool hi, const B& m, const B& o) {
+        const B x = sel(hi, o.dbl(), m.add(o));                      // lane0: a0+a1      lane1: 2 a0
+        const B y = sel(hi, m, m.template sub<16>(o));               // lane0: a0-a1+16p  lane1: a1
+        return x.mul_impl(y);
+    }
+    G16_HD static Fp2p30 zero() { return {B::zero()}; }
+    G16_HD static Fp2p30 one() { return {lane_hi() ? B::zero() : B::one()}; }
+    G16_HD Fp2p30 add(const Fp2p30& o) const { return {c.add(o.c)}; }
+    G16_HD Fp2p30 dbl() const { return {c.dbl()}; }
+    template <int K>
+    G16_HD Fp2p30 sub(const Fp2p30& o) const { return {c.template sub<K>(o.c)}; }
+    G16_HD Fp2p30 neg2() const { return {c.neg2()}; }
+    G16_HD Fp2p30 mul(const Fp2p30& o) const { return {pair_mul(lane_hi(), c, swap(c), o.c, swap(o.c))}; }
+    G16_HD Fp2p30 sqr() const { return {pair_sqr(lane_hi(), c, swap(c))}; }
+    G16_HD static bool both(bool v) { return v && (swap32(v ? 1u : 0u) != 0u); }
+    G16_HD bool maybe_zero() const { return both(c.maybe_zero()); }
+    G16_HD bool is_zero_exact() const { return both(c.is_zero_exact()); }
+    static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
+    G16_HD Fp2p30 settle() const { return *this; }
+#ifndef G16_PAIR_MIN_WAVES
+#define G16_PAIR_MIN_WAVES 2
+#endif
+#ifndef G16_PAIR_PREFETCH
+#define G16_PAIR_PREFETCH false
+#endif
+    static constexpr int ACC_MIN_WAVES = G16_PAIR_MIN_WAVES;
+    static constexpr bool ACC_PREFETCH = G16_PAIR_PREFETCH;
+    // ---- bucket-kernel hooks: two lanes per task, each touching only its half of every Fq2 value
+    static constexpr int LANES_PER_TASK = 2;
+    template <class A>
+    G16_HD static bool load_point(const A* bases, int64_t idx, Fp2p30& px, Fp2p30& py) {
+        const Fp<P>* w = reinterpret_cast<const Fp<P>*>(bases + idx);   // x.c0 x.c1 y.c0 y.c1
+        const int k = lane_hi() ? 1 : 0;
+        const Fp<P> xw = w[k], yw = w[2 + k];
+        const bool zero_half = xw.is_zero() && yw.is_zero();
+        if (both(zero_half)) return false;
+        px.c = B::unpack(xw.v);
+        py.c = B::unpack(yw.v);
+        return true;
+    }
 };
 
 // Lazy extended-Jacobian accumulator, F = Fp30<P> (G1), Fp2x30<P> or Fp2k30<P> (G2).  Invariants between
@@ -473,6 +597,22 @@ struct Acc30 {
             if ((k >> i) & 1) acc.add(*this);
         }
         return acc;
+    }
+    // bucket-kernel output: every lane of the task writes the words it owns
+    G16_HD void store_packed(XYZZ<StdF>* dst) const {
+        if constexpr (F::LANES_PER_TASK == 1) {
+            *dst = to_packed();
+        } else {
+            typedef typename F::B B30;
+            typedef typename B30::Std W;   // Fp<P>: one packed base-field element
+            W* w = reinterpret_cast<W*>(dst);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+            const int k = F::lane_hi() ? 1 : 0;
+            const W z = W::zero();
+            w[0 + k] = inf ? z : x.c.to_packed();
+            w[2 + k] = inf ? z : y.c.to_packed();
+            w[4 + k] = inf ? z : zz.c.to_packed();
+            w[6 + k] = inf ? z : zzz.c.to_packed();
+        }
     }
     // storage form between kernels: canonical coordinates in the R' domain packed in words; identity = all zero
     G16_HD XYZZ<StdF> to_packed() const {

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
                                                                           const uint32_t* __restrict__ offsets,
                                                                           const uint32_t* __restrict__ task_off, uint32_t M,
                                                                           uint32_t lmax_log, XYZZ<typename F30::Std>* __restrict__ partials) {
-    const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
+    const uint32_t t = (blockIdx.x * ACC_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
     const uint32_t ntasks = task_off[M];
     if (t >= ntasks) return;
     uint32_t lo = 0, hi = M;
@@ -230,34 +230,33 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
     Acc30<F30> acc = Acc30<F30>::identity();
     // software pipeline: the (index -> base point) gather of entry e+1 is issued before the ~20k-instruction
     // addition of entry e, so its two dependent HBM latencies hide under arithmetic
-    typedef Affine<typename F30::Std> A;
     uint32_t v_next = 0;
-    A p_next = A::identity();
+    F30 px_next = F30::zero(), py_next = F30::zero();
     bool ok_next = false;
     auto fetch = [&](uint32_t e) {
         v_next = sorted[e];
         const int64_t idx = (int64_t)(v_next & 0x7fffffffu) + shift;
         ok_next = idx >= 0 && (uint64_t)idx < base_count;
-        if (ok_next) p_next = bases[idx];
+        if (ok_next) ok_next = F30::load_point(bases, idx, px_next, py_next);
     };
     if (start < end) fetch(start);
     for (uint32_t e = start; e < end; ++e) {
         const uint32_t v = v_next;
-        const A p = p_next;
+        const F30 px = px_next;
+        F30 py = py_next;
         const bool ok = ok_next;
         if constexpr (F30::ACC_PREFETCH) {
-            if (e + 1 < end) fetch(e + 1);   // G1: -4 % measured; G2 has no registers to spare for it
+            if (e + 1 < end) fetch(e + 1);   // G1: -4 % measured
         }
-        if (!ok || p.is_identity()) continue;
-        const F30 px = F30::from_packed(p.x);
-        F30 py = F30::from_packed(p.y);
-        if (v >> 31) py = py.neg2();
-        acc.add_affine(px, py);
+        if (ok) {
+            if (v >> 31) py = py.neg2();
+            acc.add_affine(px, py);
+        }
         if constexpr (!F30::ACC_PREFETCH) {
             if (e + 1 < end) fetch(e + 1);
         }
     }
-    partials[t] = acc.to_packed();
+    acc.store_packed(&partials[t]);
 }
 
 template <class P> G16_HD Fp<P> to_r30(const Fp<P>& x) { return Fp30<P>::std_to_r30(x); }
@@ -277,10 +276,12 @@ template <class F> struct Lazy30;   // field used by the reduction kernels (and 
 template <class P> struct Lazy30<Fp<P>> { typedef Fp30<P> type; typedef Fp30<P> acc_type; };
 template <class P> struct Lazy30<Fp2<P>> {
     typedef Fp2x30<P> type;
-#ifdef G16_G2_ACC_FP2X30
+#if defined(G16_G2_ACC_FP2X30)
     typedef Fp2x30<P> acc_type;
+#elif defined(G16_G2_ACC_FP2K30)
+    typedef Fp2k30<P> acc_type;   // register-passed Karatsuba, one lane per bucket
 #else
-    typedef Fp2k30<P> acc_type;   // bucket pass: register-passed Karatsuba, no scratch operands
+    typedef Fp2p30<P> acc_type;   // bucket pass: lane-pair Fq2 (two lanes per bucket, one component each)
 #endif
 };
 
@@ -510,8 +511,9 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
     G16_TRY(arena.alloc_n((size_t)plan.W, &out->window_sums));
     if (bucket_timer) G16_TRY(bucket_timer->start(st));
     if (ss.max_tasks) {
-        hipLaunchKernelGGL((bucket_accumulate30_kernel<F30>), dim3((ss.max_tasks + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, st,
-                           d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), out->partials);
+        const uint64_t lanes = (uint64_t)ss.max_tasks * F30::LANES_PER_TASK;
+        hipLaunchKernelGGL((bucket_accumulate30_kernel<F30>), dim3((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
+                           st, d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), out->partials);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));
