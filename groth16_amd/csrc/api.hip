@@ -268,10 +268,14 @@ struct Impl {
         G16_TRY(ctx->t_wm.start(s2));
         G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s2)));
         G16_TRY(ctx->t_wm.stop(s2));
+        // h's digit/sort pass follows on stream 2 as well, so that the h bucket pass can start the moment stream 1 is free
+        ScalarSort sort_h, sort_z, sort_l;
+        G16_TRY(ctx->t_prep_h.start(s2));
+        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, s2, &sort_h)));
+        G16_TRY(ctx->t_prep_h.stop(s2));
         G16_HIP_TRY(hipEventRecord(ctx->ev_h, s2));
 
         // ---- stream 1: assignment = full_assignment[1..] (prover.rs:80-85): ONE digit/sort pass for a, b_g1, b_g2 (and l)
-        ScalarSort sort_h, sort_z, sort_l;
         G16_TRY(ctx->t_prep_z.start(s1));
         G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, ctx->arena, s1, &sort_z)));
         G16_TRY(ctx->t_prep_z.stop(s1));
@@ -317,9 +321,6 @@ struct Impl {
         if (!skip_b_g1) G16_TRY(run_msm(3, pk->b_g1, 0, pk->b_g1_count, sort_z, &buf_b1));                  // prover.rs:98-108
         // ---- h_acc = msm(h_query, h) (prover.rs:63-66): needs the witness map
         G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_h, 0));
-        G16_TRY(ctx->t_prep_h.start(s1));
-        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, s1, &sort_h)));
-        G16_TRY(ctx->t_prep_h.stop(s1));
         G16_TRY(run_msm(0, pk->h, 0, pk->h_count, sort_h, &buf_h));
 
         // ---- host: fold sum_w 2^(cw) R_w per MSM as its window sums arrive (the GPU is still busy with later MSMs)
@@ -867,8 +868,12 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
     c->curve = curve;
     c->device = device_id;
     memset(&c->tm, 0, sizeof(c->tm));
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+    // stream 2 carries the short, latency-bound work on the critical path of the h MSM (witness map, digit/sort, reductions):
+    // give it priority over the long bucket passes it runs underneath
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lower = higher priority
+    bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 5; ++i)

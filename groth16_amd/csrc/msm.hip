@@ -97,45 +97,90 @@ __global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const uint16
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. scan (single workgroup; M = W*B <= 2^19 entries)
+// 3. scan over the M = W*B bucket counts: bucket offsets (entries) and task offsets (ceil(count / Lmax)),
+//    three small launches (block sums -> scan of block sums -> write), 2048 counts per workgroup, coalesced
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t* __restrict__ counts, uint32_t M, uint32_t lmax_log,
-                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ task_off,
-                                                           uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
-    __shared__ uint32_t sa[1024], sb[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t seg = (M + 1023) / 1024;
-    const uint32_t lo = min(M, tid * seg), hi = min(M, lo + seg);
+static constexpr int SCAN_THREADS = 256;
+static constexpr int SCAN_PER_THREAD = 8;
+static constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
+
+__device__ __forceinline__ void scan_load(const uint32_t* __restrict__ counts, uint32_t M, uint32_t base, uint32_t lmax_log,
+                                          uint32_t (&cv)[SCAN_PER_THREAD], uint32_t& sumA, uint32_t& sumB) {
     const uint32_t lmask = (1u << lmax_log) - 1u;
-    uint32_t sumA = 0, sumB = 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t v = counts[i];
-        sumA += v;
-        sumB += (v + lmask) >> lmax_log;
+    sumA = 0; sumB = 0;
+    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) {
+        const uint32_t i = base + j;
+        cv[j] = i < M ? counts[i] : 0u;
+        sumA += cv[j];
+        sumB += (cv[j] + lmask) >> lmax_log;
     }
-    sa[tid] = sumA;
-    sb[tid] = sumB;
+}
+
+// exclusive scan of one value per thread across the workgroup; returns the workgroup total through *total
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* sh, uint32_t* total) {
+    const uint32_t tid = threadIdx.x;
+    sh[tid] = v;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t va = tid >= d ? sa[tid - d] : 0u, vb = tid >= d ? sb[tid - d] : 0u;
+    for (uint32_t d = 1; d < SCAN_THREADS; d <<= 1) {
+        const uint32_t add = tid >= d ? sh[tid - d] : 0u;
         __syncthreads();
-        sa[tid] += va;
-        sb[tid] += vb;
+        sh[tid] += add;
         __syncthreads();
     }
-    uint32_t baseA = sa[tid] - sumA, baseB = sb[tid] - sumB;
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t v = counts[i];
-        offsets[i] = baseA;
-        task_off[i] = baseB;
-        baseA += v;
-        baseB += (v + lmask) >> lmax_log;
-        // a bucket split over several tasks needs its partial sums combined before the bucket reduction
-        if (v > (1u << lmax_log)) heavy[1 + atomicAdd(&heavy[0], 1u)] = i;
+    const uint32_t incl = sh[tid];
+    *total = sh[SCAN_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ counts, uint32_t M, uint32_t lmax_log,
+                                                                       uint32_t* __restrict__ block_sums /* [2 * nblocks] */) {
+    __shared__ uint32_t sa[SCAN_THREADS], sb[SCAN_THREADS];
+    uint32_t cv[SCAN_PER_THREAD], sumA, sumB, totA, totB;
+    scan_load(counts, M, blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD, lmax_log, cv, sumA, sumB);
+    (void)block_exclusive(sumA, sa, &totA);
+    (void)block_exclusive(sumB, sb, &totB);
+    if (threadIdx.x == 0) { block_sums[2 * blockIdx.x] = totA; block_sums[2 * blockIdx.x + 1] = totB; }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_offsets_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t M,
+                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ task_off) {
+    // nblocks <= 256 for M <= 2^19; loop for safety
+    __shared__ uint32_t sa[SCAN_THREADS], sb[SCAN_THREADS];
+    uint32_t carryA = 0, carryB = 0;
+    for (uint32_t base = 0; base < nblocks; base += SCAN_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t a = i < nblocks ? block_sums[2 * i] : 0u, b = i < nblocks ? block_sums[2 * i + 1] : 0u;
+        uint32_t totA, totB;
+        const uint32_t ea = block_exclusive(a, sa, &totA), eb = block_exclusive(b, sb, &totB);
+        if (i < nblocks) { block_sums[2 * i] = carryA + ea; block_sums[2 * i + 1] = carryB + eb; }
+        carryA += totA;
+        carryB += totB;
     }
-    if (tid == 1023) {
-        offsets[M] = sa[1023];
-        task_off[M] = sb[1023];
+    if (threadIdx.x == 0) { offsets[M] = carryA; task_off[M] = carryB; }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const uint32_t* __restrict__ counts, uint32_t M, uint32_t lmax_log,
+                                                                  const uint32_t* __restrict__ block_base, uint32_t* __restrict__ offsets,
+                                                                  uint32_t* __restrict__ task_off,
+                                                                  uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
+    __shared__ uint32_t sa[SCAN_THREADS], sb[SCAN_THREADS];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    const uint32_t lmask = (1u << lmax_log) - 1u;
+    uint32_t cv[SCAN_PER_THREAD], sumA, sumB, totA, totB;
+    scan_load(counts, M, base, lmax_log, cv, sumA, sumB);
+    uint32_t a = block_base[2 * blockIdx.x] + block_exclusive(sumA, sa, &totA);
+    uint32_t b = block_base[2 * blockIdx.x + 1] + block_exclusive(sumB, sb, &totB);
+    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) {
+        const uint32_t i = base + j;
+        if (i < M) {
+            offsets[i] = a;
+            task_off[i] = b;
+            a += cv[j];
+            b += (cv[j] + lmask) >> lmax_log;
+            // a bucket split over several tasks needs its partial sums combined before the bucket reduction
+            if (cv[j] > (1u << lmax_log)) heavy[1 + atomicAdd(&heavy[0], 1u)] = i;
+        }
     }
 }
 
@@ -486,9 +531,18 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
                            counts);
         G16_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, counts, M, (uint32_t)ilog2(plan.Lmax), out->offsets, out->task_off,
-                       out->heavy);
-    G16_LAUNCH_CHECK();
+    {
+        const uint32_t nblocks = (M + SCAN_TILE - 1) / SCAN_TILE, lml = (uint32_t)ilog2(plan.Lmax);
+        uint32_t* block_sums = nullptr;
+        G16_TRY(arena.alloc_n((size_t)2 * nblocks, &block_sums));
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, counts, M, lml, block_sums);
+        G16_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nblocks, M, out->offsets, out->task_off);
+        G16_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, counts, M, lml, block_sums, out->offsets, out->task_off,
+                           out->heavy);
+        G16_LAUNCH_CHECK();
+    }
     if (n) {
         const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
