@@ -9,6 +9,7 @@
 #include "msm_common.hpp"
 #include "fp30.hpp"
 #include <chrono>
+#include <future>
 #include <new>
 #include <type_traits>
 
@@ -390,25 +391,35 @@ struct Impl {
         (r * s).to_canonical(rsk);
         const int nb = Fr::Params::BITS;
         const G1X delta1 = G1X::from_affine(pk.delta_g1);
-        const G1X r_s_delta_g1 = delta1.mul_bits(rsk, nb);                      // :76
-        // g_a = r*delta_g1 + a_query[0] + msm + alpha_g1   (calculate_coeff, :90-92, :252-270)
+        // three independent chains of scalar multiplications (the only non-trivial host work): run them on host threads
+        // B in G2:  s*delta_g2 + b_g2_query[0] + msm + beta_g2                       (:112-113)
+        auto fut_b2 = std::async(std::launch::async, [&]() {
+            G2X g2_b = G2X::from_affine(pk.delta_g2).mul_bits(sk, nb);
+            g2_b.add_affine(pk.b_g2_query0);
+            g2_b.add(b2_msm);
+            g2_b.add_affine(pk.beta_g2);
+            return g2_b;
+        });
+        // r * B in G1, skipped when r == 0                                            (:98-108, :114)
+        auto fut_rb1 = std::async(std::launch::async, [&]() {
+            G1X g1_b = G1X::identity();
+            if (!r.is_zero()) {
+                g1_b = delta1.mul_bits(sk, nb);
+                g1_b.add_affine(pk.b_g1_query0);
+                g1_b.add(b1_msm);
+                g1_b.add_affine(pk.beta_g1);
+            }
+            return g1_b.mul_bits(rk, nb);
+        });
+        // g_a = r*delta_g1 + a_query[0] + msm + alpha_g1   (calculate_coeff, :90-92, :252-270), then s*g_a (:94)
         G1X g_a = delta1.mul_bits(rk, nb);
         g_a.add_affine(pk.a_query0);
         g_a.add(a_msm);
         g_a.add_affine(pk.alpha_g1);
-        const G1X s_g_a = g_a.mul_bits(sk, nb);                                 // :94
-        G1X g1_b = G1X::identity();
-        if (!r.is_zero()) {                                                    // :98-108
-            g1_b = delta1.mul_bits(sk, nb);
-            g1_b.add_affine(pk.b_g1_query0);
-            g1_b.add(b1_msm);
-            g1_b.add_affine(pk.beta_g1);
-        }
-        G2X g2_b = G2X::from_affine(pk.delta_g2).mul_bits(sk, nb);             // :112-113
-        g2_b.add_affine(pk.b_g2_query0);
-        g2_b.add(b2_msm);
-        g2_b.add_affine(pk.beta_g2);
-        const G1X r_g1_b = g1_b.mul_bits(rk, nb);                               // :114
+        const G1X s_g_a = g_a.mul_bits(sk, nb);
+        const G1X r_s_delta_g1 = delta1.mul_bits(rsk, nb);                      // :76
+        const G1X r_g1_b = fut_rb1.get();
+        const G2X g2_b = fut_b2.get();
         G1X g_c = s_g_a;                                                        // :119-124
         g_c.add(r_g1_b);
         g_c.add(r_s_delta_g1.neg());
@@ -612,7 +623,7 @@ struct Impl {
                 buckets[(size_t)w * plan.B + bucket].add_affine(q);
             }
         }
-        const uint32_t G = plan.B >= 16 ? 16u : plan.B, cpw = plan.B / G;
+        const uint32_t G = plan.B >= 8 ? 8u : plan.B, cpw = plan.B / G;
         std::vector<X> wsum(plan.W, X::identity());
         for (int w = 0; w < plan.W; ++w) {
             for (uint32_t ch = 0; ch < cpw; ++ch) {

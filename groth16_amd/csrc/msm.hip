@@ -38,7 +38,8 @@ namespace g16 {
 static constexpr int SORT_THREADS = 1024;
 static constexpr int ACC_THREADS = 128;
 static constexpr int RED_THREADS = 64;
-static constexpr uint32_t REDUCE_G = 16;  // buckets per lane in the bucket reduction
+static constexpr int WIN_THREADS = 256;  // lanes of the per-window reduction
+static constexpr uint32_t REDUCE_G = 8;   // buckets per lane in the bucket reduction
 
 struct PlanDev {
     int c, W;
@@ -389,16 +390,16 @@ __global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const XYZZ<t
 }
 
 template <class F30>
-__global__ __launch_bounds__(RED_THREADS) void window_reduce_kernel(const XYZZ<typename F30::Std>* __restrict__ chunk_out, uint32_t cpw,
+__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const XYZZ<typename F30::Std>* __restrict__ chunk_out, uint32_t cpw,
                                                                     XYZZ<typename F30::Std>* __restrict__ window_sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<typename F30::Std>* sh = reinterpret_cast<XYZZ<typename F30::Std>*>(smem);
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     Acc30<F30> acc = Acc30<F30>::identity();
-    for (uint32_t j = tid; j < cpw; j += RED_THREADS) acc.add(Acc30<F30>::from_packed(chunk_out[(uint64_t)w * cpw + j]));
+    for (uint32_t j = tid; j < cpw; j += WIN_THREADS) acc.add(Acc30<F30>::from_packed(chunk_out[(uint64_t)w * cpw + j]));
     sh[tid] = acc.to_packed();
     __syncthreads();
-    for (uint32_t d = RED_THREADS / 2; d > 0; d >>= 1) {
+    for (uint32_t d = WIN_THREADS / 2; d > 0; d >>= 1) {
         if (tid < d) {
             Acc30<F30> x = Acc30<F30>::from_packed(sh[tid]);
             x.add(Acc30<F30>::from_packed(sh[tid + d]));
@@ -581,10 +582,12 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
     static bool attr_set = false;
-    const size_t lds_heavy = sizeof(XYZZ<F>) * HEAVY_THREADS, lds_win = sizeof(XYZZ<F>) * RED_THREADS;
+    const size_t lds_heavy = sizeof(XYZZ<F>) * HEAVY_THREADS, lds_win = sizeof(XYZZ<F>) * WIN_THREADS;
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&heavy_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_heavy));
+        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_win));
         attr_set = true;
     }
     hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, buf.partials, ss.task_off, ss.heavy);
@@ -592,7 +595,7 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, buf.partials,
                        ss.task_off, plan.B, plan.W, G, buf.chunk_out);
     G16_LAUNCH_CHECK();
-    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.W), dim3(RED_THREADS), lds_win, st, buf.chunk_out, cpw, buf.window_sums);
+    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.W), dim3(WIN_THREADS), lds_win, st, buf.chunk_out, cpw, buf.window_sums);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
