@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--cpu-log2", type=int, default=int(os.environ.get("G16_BENCH_CPU_LOG2", "18")))
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("G16_BENCH_CPU_THREADS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sim-shards", type=int, default=0,
+                    help="DIAGNOSTIC, not a benchmark: time one rank's share of an N-way sharded proof on a single GPU "
+                         "(shard 0 of N, no exchange); the JSON line is tagged and must not be read as throughput")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,6 +205,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    # test-only knobs (tests/test_gpu_parity.py::test_bench_two_ranks_one_gpu): run the N > 1 code path on a 1-GPU box by
+    # putting every rank on device 0 and exchanging over gloo (RCCL refuses two ranks on one device)
+    backend = os.environ.get("G16_BENCH_BACKEND", "nccl")
+    if os.environ.get("G16_BENCH_FORCE_DEVICE0"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     dist = None
@@ -209,14 +217,37 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
+            device = torch.device("cpu")  # tensors handed to the collective live on the host for gloo
         dist = dist_mod
+
+    gpu = torch.device(f"cuda:{local_rank}")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.sim_shards:
+        assert world == 1
+        p = DeviceProver(args.curve, args.log2, 1, 0, args.sim_shards, local_rank)
+        for _ in range(args.warmup):
+            p.partial()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            part = p.partial()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        t1 = time.perf_counter()
+        p.finalize([part] * args.sim_shards)
+        fin = time.perf_counter() - t1
+        print(json.dumps({"diagnostic": "per-rank share of a sharded proof (NOT a throughput number)", "sim_shards": args.sim_shards,
+                          "log2": args.log2, "partial_ms": 1e3 * dt, "finalize_ms": 1e3 * fin, "phases": p.timings()}), flush=True)
+        return
     p = DeviceProver(args.curve, args.log2, 1, rank, world, local_rank)
     proof = None
     for _ in range(args.warmup):
@@ -239,7 +270,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # every rank must have produced the same proof
-        pt = torch.from_numpy(proof.view(np.int64)).to(device)
+        pt = torch.from_numpy(proof.view(np.int64).copy()).to(device)
         gathered = [torch.empty_like(pt) for _ in range(world)]
         dist.all_gather(gathered, pt)
         assert all(bool((x == gathered[0]).all()) for x in gathered), "ranks disagree on the proof"
@@ -280,6 +311,10 @@ def main():
             "roofline": roofline,
             "phases_ms_per_step": {k_: round(v / args.steps, 3) for k_, v in phase_acc.items()},
         }
+        if os.environ.get("G16_BENCH_PRINT_PROOF"):
+            import hashlib
+
+            out["proof_sha256"] = hashlib.sha256(proof.tobytes()).hexdigest()
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.curve, args.cpu_log2, 1, args.cpu_threads)

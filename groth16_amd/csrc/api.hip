@@ -262,19 +262,24 @@ struct Impl {
         G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
         G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));
 
-        // ---- stream 2: witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it
+        // ---- witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it.
+        // Whole key on this GPU: it runs on stream 2 underneath the (much longer) bucket passes.  Sharded key (this rank
+        // holds < 1/3 of the bases, but the witness map is replicated at full size): the bucket passes are too short to
+        // hide it and their long-lived waves would starve it, so it goes first, alone, on stream 1.
         Fr* d_h = nullptr;
         G16_TRY(ctx->arena.alloc_n(n, &d_h));
-        G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
-        G16_TRY(ctx->t_wm.start(s2));
-        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s2)));
-        G16_TRY(ctx->t_wm.stop(s2));
-        // h's digit/sort pass follows on stream 2 as well, so that the h bucket pass can start the moment stream 1 is free
+        const bool sharded = pk->a_count * 3 < m;
+        hipStream_t s_wm = sharded ? s1 : s2;
+        if (!sharded) G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
+        G16_TRY(ctx->t_wm.start(s_wm));
+        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s_wm)));
+        G16_TRY(ctx->t_wm.stop(s_wm));
+        // h's digit/sort pass follows on the same stream, so that the h bucket pass can start the moment stream 1 is free
         ScalarSort sort_h, sort_z, sort_l;
-        G16_TRY(ctx->t_prep_h.start(s2));
-        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, s2, &sort_h)));
-        G16_TRY(ctx->t_prep_h.stop(s2));
-        G16_HIP_TRY(hipEventRecord(ctx->ev_h, s2));
+        G16_TRY(ctx->t_prep_h.start(s_wm));
+        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, s_wm, &sort_h)));
+        G16_TRY(ctx->t_prep_h.stop(s_wm));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_h, s_wm));
 
         // ---- stream 1: assignment = full_assignment[1..] (prover.rs:80-85): ONE digit/sort pass for a, b_g1, b_g2 (and l)
         G16_TRY(ctx->t_prep_z.start(s1));

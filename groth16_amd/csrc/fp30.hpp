@@ -201,6 +201,12 @@ struct Fp30 {
     }
     // value < 32p  ->  value < 2p  (same residue)
     G16_HD Fp30 weak_reduce32() const { return cond_sub<16>().template cond_sub<8>().template cond_sub<4>().template cond_sub<2>(); }
+    G16_HD bool raw_zero() const {
+        uint32_t a = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) a |= l[i];
+        return a == 0;
+    }
+    typedef Fp30 Raw;   // the one-lane field whose limb layout partial sums are stored in
     // accumulator trait constants (see Acc30): bounds of this field's product outputs are < 1.5p
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD Fp30 settle() const { return *this; }
@@ -322,6 +328,8 @@ struct Fp2x30 {
     G16_HD Std to_packed() const { return {c0.to_packed(), c1.to_packed()}; }
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD Fp2x30 settle() const { return *this; }
+    G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
+    typedef Fp2x30 Raw;
     static constexpr int ACC_MIN_WAVES = 1;
     static constexpr bool ACC_PREFETCH = false;
     // ---- bucket-kernel hooks: one lane per task
@@ -379,6 +387,8 @@ struct Fp2k30 {
     // product outputs < 6p -> subtract them with K = 8 (16 when doubled); x, y are settled below 2p
     static constexpr int KM = 8, K2M = 16, KX = 2, KY = 2;
     G16_HD Fp2k30 settle() const { return {c0.weak_reduce32(), c1.weak_reduce32()}; }
+    G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
+    typedef Fp2x30<P> Raw;
 #ifndef G16_G2_MIN_WAVES
 #define G16_G2_MIN_WAVES 1
 #endif
@@ -465,6 +475,7 @@ struct Fp2p30 {
     G16_HD bool is_zero_exact() const { return both(c.is_zero_exact()); }
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD Fp2p30 settle() const { return *this; }
+    typedef Fp2x30<P> Raw;
 #ifndef G16_PAIR_MIN_WAVES
 #define G16_PAIR_MIN_WAVES 2
 #endif
@@ -486,6 +497,14 @@ struct Fp2p30 {
         py.c = B::unpack(yw.v);
         return true;
     }
+};
+
+// Partial sums between the MSM kernels: the accumulator's lazy limbs verbatim (no conversion, no product), in the layout of
+// the one-lane field R (Fp30 for G1: 208 B; Fp2x30 for G2: 416 B).  Identity <=> zz is all-zero limbs (a non-identity zz is
+// a product of non-zero residues, so its limbs cannot all vanish).
+template <class R>
+struct alignas(16) AccRaw {
+    R x, y, zz, zzz;
 };
 
 // Lazy extended-Jacobian accumulator, F = Fp30<P> (G1), Fp2x30<P> or Fp2k30<P> (G2).  Invariants between
@@ -597,6 +616,28 @@ struct Acc30 {
             if ((k >> i) & 1) acc.add(*this);
         }
         return acc;
+    }
+    // raw limb storage (see AccRaw): every lane of the task writes the limbs it owns
+    G16_HD void store_raw(AccRaw<typename F::Raw>* dst) const {
+        typedef typename F::Raw R;
+        if constexpr (F::LANES_PER_TASK == 1) {
+            static_assert(sizeof(F) == sizeof(R), "one-lane fields share the raw layout");
+            F* w = reinterpret_cast<F*>(dst);
+            w[0] = x; w[1] = y; w[2] = inf ? F::zero() : zz; w[3] = zzz;
+        } else {
+            typedef typename F::B B30;
+            B30* w = reinterpret_cast<B30*>(dst);   // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+            const int k = F::lane_hi() ? 1 : 0;
+            w[0 + k] = x.c; w[2 + k] = y.c; w[4 + k] = inf ? B30::zero() : zz.c; w[6 + k] = zzz.c;
+        }
+    }
+    G16_HD static Acc30 load_raw(const AccRaw<typename F::Raw>& p) {
+        static_assert(F::LANES_PER_TASK == 1, "raw partials are consumed by one-lane kernels");
+        const F* w = reinterpret_cast<const F*>(&p);
+        Acc30 a;
+        a.x = w[0]; a.y = w[1]; a.zz = w[2]; a.zzz = w[3];
+        a.inf = a.zz.raw_zero();
+        return a;
     }
     // bucket-kernel output: every lane of the task writes the words it owns
     G16_HD void store_packed(XYZZ<StdF>* dst) const {

@@ -110,7 +110,7 @@ struct MsmPlan {
     int c = 0;          // window bits (<= 16)
     int W = 0;          // windows
     uint32_t B = 0;     // buckets per window = 2^(c-1)
-    uint32_t Lmax = 0;  // max sorted entries one accumulation task walks
+    uint32_t Lmax = 0;  // segment length: sorted entries one bucket-pass lane walks (power of two)
     uint32_t chunk = 0; // points per histogram/scatter block
     uint32_t K[10];     // signed-digit bias  sum_w 2^(c-1) 2^(cw)
 };
@@ -123,9 +123,10 @@ struct ScalarSort {
     uint64_t n = 0;
     uint32_t* sorted = nullptr;    // [<= n*W] point index | sign<<31, grouped by (window, bucket)
     uint32_t* offsets = nullptr;   // [W*B + 1] exclusive prefix of bucket sizes
-    uint32_t* task_off = nullptr;  // [W*B + 1] exclusive prefix of per-bucket task counts
-    uint32_t* heavy = nullptr;     // [0] = number of buckets split over several tasks, then their ids
-    uint32_t max_tasks = 0;        // host-side upper bound on task_off[W*B]
+    uint32_t* task_off = nullptr;  // [W*B + 1] exclusive prefix of per-bucket partial-sum slots (one per segment a bucket touches)
+    uint32_t* heavy = nullptr;     // [0] = number of buckets with more than HEAVY_PARTS partials, then their ids
+    uint32_t max_tasks = 0;        // host-side upper bound on task_off[W*B] (partial slots)
+    uint32_t max_segments = 0;     // host-side upper bound on ceil(sorted entries / Lmax)
 };
 template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipStream_t st, ScalarSort* out);
 
@@ -137,8 +138,8 @@ template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n,
 //                    Montgomery form, XYZZ) in buf.window_sums.
 template <class F>
 struct MsmBuffers {
-    XYZZ<F>* partials = nullptr;
-    XYZZ<F>* chunk_out = nullptr;
+    void* partials = nullptr;    // AccRaw records (lazy limbs), one per (bucket, segment) pair
+    void* chunk_out = nullptr;   // AccRaw records, one per reduction chunk
     XYZZ<F>* window_sums = nullptr;
 };
 template <class F> int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena,

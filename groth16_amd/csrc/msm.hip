@@ -98,24 +98,14 @@ __global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const uint16
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. scan over the M = W*B bucket counts: bucket offsets (entries) and task offsets (ceil(count / Lmax)),
-//    three small launches (block sums -> scan of block sums -> write), 2048 counts per workgroup, coalesced
+// 3. scans over the M = W*B buckets: an exclusive prefix sum of a u32 array in three small coalesced launches
+//    (block sums -> scan of block sums -> write), 2048 values per workgroup.  Used twice: bucket counts -> bucket
+//    offsets, and per-bucket partial-slot counts -> slot offsets.
 // ---------------------------------------------------------------------------------------------
 static constexpr int SCAN_THREADS = 256;
 static constexpr int SCAN_PER_THREAD = 8;
 static constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
-
-__device__ __forceinline__ void scan_load(const uint32_t* __restrict__ counts, uint32_t M, uint32_t base, uint32_t lmax_log,
-                                          uint32_t (&cv)[SCAN_PER_THREAD], uint32_t& sumA, uint32_t& sumB) {
-    const uint32_t lmask = (1u << lmax_log) - 1u;
-    sumA = 0; sumB = 0;
-    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) {
-        const uint32_t i = base + j;
-        cv[j] = i < M ? counts[i] : 0u;
-        sumA += cv[j];
-        sumB += (cv[j] + lmask) >> lmax_log;
-    }
-}
+static constexpr uint32_t HEAVY_PARTS = 8;   // a bucket with more partial sums than this is combined cooperatively
 
 // exclusive scan of one value per thread across the workgroup; returns the workgroup total through *total
 __device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* sh, uint32_t* total) {
@@ -134,55 +124,52 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* sh, ui
     return incl - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ counts, uint32_t M, uint32_t lmax_log,
-                                                                       uint32_t* __restrict__ block_sums /* [2 * nblocks] */) {
-    __shared__ uint32_t sa[SCAN_THREADS], sb[SCAN_THREADS];
-    uint32_t cv[SCAN_PER_THREAD], sumA, sumB, totA, totB;
-    scan_load(counts, M, blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD, lmax_log, cv, sumA, sumB);
-    (void)block_exclusive(sumA, sa, &totA);
-    (void)block_exclusive(sumB, sb, &totB);
-    if (threadIdx.x == 0) { block_sums[2 * blockIdx.x] = totA; block_sums[2 * blockIdx.x + 1] = totB; }
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ vals, uint32_t M,
+                                                                       uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t sa[SCAN_THREADS];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t sum = 0, tot;
+    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) sum += (base + j < M) ? vals[base + j] : 0u;
+    (void)block_exclusive(sum, sa, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_offsets_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t M,
-                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ task_off) {
-    // nblocks <= 256 for M <= 2^19; loop for safety
-    __shared__ uint32_t sa[SCAN_THREADS], sb[SCAN_THREADS];
-    uint32_t carryA = 0, carryB = 0;
+                                                                          uint32_t* __restrict__ prefix) {
+    __shared__ uint32_t sa[SCAN_THREADS];
+    uint32_t carry = 0;
     for (uint32_t base = 0; base < nblocks; base += SCAN_THREADS) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t a = i < nblocks ? block_sums[2 * i] : 0u, b = i < nblocks ? block_sums[2 * i + 1] : 0u;
-        uint32_t totA, totB;
-        const uint32_t ea = block_exclusive(a, sa, &totA), eb = block_exclusive(b, sb, &totB);
-        if (i < nblocks) { block_sums[2 * i] = carryA + ea; block_sums[2 * i + 1] = carryB + eb; }
-        carryA += totA;
-        carryB += totB;
+        const uint32_t a = i < nblocks ? block_sums[i] : 0u;
+        uint32_t tot;
+        const uint32_t ea = block_exclusive(a, sa, &tot);
+        if (i < nblocks) block_sums[i] = carry + ea;
+        carry += tot;
     }
-    if (threadIdx.x == 0) { offsets[M] = carryA; task_off[M] = carryB; }
+    if (threadIdx.x == 0) prefix[M] = carry;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const uint32_t* __restrict__ counts, uint32_t M, uint32_t lmax_log,
-                                                                  const uint32_t* __restrict__ block_base, uint32_t* __restrict__ offsets,
-                                                                  uint32_t* __restrict__ task_off,
-                                                                  uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
-    __shared__ uint32_t sa[SCAN_THREADS], sb[SCAN_THREADS];
+__global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const uint32_t* __restrict__ vals, uint32_t M,
+                                                                  const uint32_t* __restrict__ block_base, uint32_t* __restrict__ prefix) {
+    __shared__ uint32_t sa[SCAN_THREADS];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
-    const uint32_t lmask = (1u << lmax_log) - 1u;
-    uint32_t cv[SCAN_PER_THREAD], sumA, sumB, totA, totB;
-    scan_load(counts, M, base, lmax_log, cv, sumA, sumB);
-    uint32_t a = block_base[2 * blockIdx.x] + block_exclusive(sumA, sa, &totA);
-    uint32_t b = block_base[2 * blockIdx.x + 1] + block_exclusive(sumB, sb, &totB);
+    uint32_t cv[SCAN_PER_THREAD], sum = 0, tot;
+    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) { cv[j] = (base + j < M) ? vals[base + j] : 0u; sum += cv[j]; }
+    uint32_t a = block_base[blockIdx.x] + block_exclusive(sum, sa, &tot);
     G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) {
-        const uint32_t i = base + j;
-        if (i < M) {
-            offsets[i] = a;
-            task_off[i] = b;
-            a += cv[j];
-            b += (cv[j] + lmask) >> lmax_log;
-            // a bucket split over several tasks needs its partial sums combined before the bucket reduction
-            if (cv[j] > (1u << lmax_log)) heavy[1 + atomicAdd(&heavy[0], 1u)] = i;
-        }
+        if (base + j < M) { prefix[base + j] = a; a += cv[j]; }
     }
+}
+
+// partial-sum slots of bucket b = number of length-L segments of the sorted list its entries touch
+__global__ void bucket_slots_kernel(const uint32_t* __restrict__ offsets, uint32_t M, uint32_t lseg_log, uint32_t* __restrict__ nparts,
+                                    uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= M) return;
+    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    const uint32_t np = hi > lo ? (((hi - 1) >> lseg_log) - (lo >> lseg_log) + 1u) : 0u;
+    nparts[b] = np;
+    if (np > HEAVY_PARTS) heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -251,28 +238,29 @@ __global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate_kernel(const Af
     partials[t] = acc;
 }
 
-// Production variant on the 30-bit lazy arithmetic (fp30.hpp), F30 = Fp30<P> (G1) or Fp2x30<P> (G2).
-// `bases` hold canonical x*R', y*R' packed in 32-bit words (convert_bases30_kernel); partial sums are
-// stored in the same R' domain (XYZZ, canonical, packed) and only the W window sums are converted to
-// the standard arkworks radix for the host.
+// 5. bucket accumulation (THE hot kernel), 30-bit lazy arithmetic (fp30.hpp); F30 = Fp30<P> (G1) or Fp2p30<P> (G2, lane pair).
+// Work unit = a SEGMENT of Lseg consecutive entries of the bucket-sorted list, not a bucket: every lane walks exactly
+// Lseg entries, so lanes of a wave finish together whatever the bucket-size distribution (one lane per bucket left ~18 %
+// of lane time idle at a mean bucket load of 128, ~35 % at 16).  When the walk crosses a bucket boundary the running sum
+// is flushed -- raw lazy limbs, no conversion -- into that bucket's slot for this segment (slot offsets from the scan),
+// so a bucket ends up with one partial sum per segment it touches; the reduction kernels add them up.
+// `bases` hold canonical x*R', y*R' packed in 32-bit words (convert_bases30_kernel).
 template <class F30>
-__global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(const Affine<typename F30::Std>* __restrict__ bases,
-                                                                          int64_t shift, uint64_t base_count,
-                                                                          const uint32_t* __restrict__ sorted,
-                                                                          const uint32_t* __restrict__ offsets,
-                                                                          const uint32_t* __restrict__ task_off, uint32_t M,
-                                                                          uint32_t lmax_log, XYZZ<typename F30::Std>* __restrict__ partials) {
+__global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(
+    const Affine<typename F30::Std>* __restrict__ bases, int64_t shift, uint64_t base_count, const uint32_t* __restrict__ sorted,
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ slot_off, uint32_t M, uint32_t lseg_log,
+    AccRaw<typename F30::Raw>* __restrict__ partials) {
     const uint32_t t = (blockIdx.x * ACC_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
-    const uint32_t ntasks = task_off[M];
-    if (t >= ntasks) return;
-    uint32_t lo = 0, hi = M;
+    const uint32_t S = offsets[M];                                                          // sorted entries in total
+    const uint32_t start = t << lseg_log;
+    if (start >= S) return;
+    const uint32_t end = min(S, start + (1u << lseg_log));
+    uint32_t lo = 0, hi = M;  // bucket containing `start`: offsets[lo] <= start < offsets[lo + 1]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (task_off[mid] <= t) lo = mid; else hi = mid;
+        if (offsets[mid] <= start) lo = mid; else hi = mid;
     }
-    const uint32_t k = t - task_off[lo];
-    const uint32_t start = offsets[lo] + (k << lmax_log);
-    const uint32_t end = min(offsets[lo + 1], start + (1u << lmax_log));
+    uint32_t b = lo, b_first = offsets[b], b_end = offsets[b + 1];
     Acc30<F30> acc = Acc30<F30>::identity();
     // software pipeline: the (index -> base point) gather of entry e+1 is issued before the ~20k-instruction
     // addition of entry e, so its two dependent HBM latencies hide under arithmetic
@@ -285,14 +273,20 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         ok_next = idx >= 0 && (uint64_t)idx < base_count;
         if (ok_next) ok_next = F30::load_point(bases, idx, px_next, py_next);
     };
-    if (start < end) fetch(start);
+    fetch(start);
     for (uint32_t e = start; e < end; ++e) {
+        if (e == b_end) {  // crossed into the next non-empty bucket: flush this segment's share of bucket b
+            acc.store_raw(&partials[slot_off[b] + (t - (b_first >> lseg_log))]);
+            acc = Acc30<F30>::identity();
+            do { ++b; b_end = offsets[b + 1]; } while (b_end <= e);
+            b_first = offsets[b];
+        }
         const uint32_t v = v_next;
         const F30 px = px_next;
         F30 py = py_next;
         const bool ok = ok_next;
         if constexpr (F30::ACC_PREFETCH) {
-            if (e + 1 < end) fetch(e + 1);   // G1: -4 % measured
+            if (e + 1 < end) fetch(e + 1);
         }
         if (ok) {
             if (v >> 31) py = py.neg2();
@@ -302,7 +296,7 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
             if (e + 1 < end) fetch(e + 1);
         }
     }
-    acc.store_packed(&partials[t]);
+    acc.store_raw(&partials[slot_off[b] + (t - (b_first >> lseg_log))]);
 }
 
 template <class P> G16_HD Fp<P> to_r30(const Fp<P>& x) { return Fp30<P>::std_to_r30(x); }
@@ -332,33 +326,32 @@ template <class P> struct Lazy30<Fp2<P>> {
 };
 
 // ---------------------------------------------------------------------------------------------
-// 5b. heavy buckets: a bucket that was split over several tasks (short top window, repeated
-//     scalars such as the all-equal witness of benches/bench.rs:52-54, ...) has its partial sums
-//     combined cooperatively by one workgroup; the result replaces the bucket's first partial.
+// 5b. heavy buckets: a bucket with many partial sums (short top window, repeated scalars such as the all-equal
+//     witness of benches/bench.rs:52-54, a boolean witness, ...) has them combined cooperatively by one workgroup; the
+//     result replaces the bucket's first partial (the bucket reduction reads only that one for such buckets).
 // ---------------------------------------------------------------------------------------------
 static constexpr int HEAVY_THREADS = 128;
 static constexpr int HEAVY_BLOCKS = 512;
 
 template <class F30>
-__global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(XYZZ<typename F30::Std>* __restrict__ partials,
-                                                                     const uint32_t* __restrict__ task_off,
+__global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(AccRaw<F30>* __restrict__ partials, const uint32_t* __restrict__ slot_off,
                                                                      const uint32_t* __restrict__ heavy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    XYZZ<typename F30::Std>* sh = reinterpret_cast<XYZZ<typename F30::Std>*>(smem);
+    AccRaw<F30>* sh = reinterpret_cast<AccRaw<F30>*>(smem);
     const uint32_t nheavy = heavy[0], tid = threadIdx.x;
     for (uint32_t i = blockIdx.x; i < nheavy; i += gridDim.x) {
         const uint32_t b = heavy[1 + i];
-        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        const uint32_t t0 = slot_off[b], t1 = slot_off[b + 1];
         Acc30<F30> acc = Acc30<F30>::identity();
-        for (uint32_t q = t0 + tid; q < t1; q += HEAVY_THREADS) acc.add(Acc30<F30>::from_packed(partials[q]));
+        for (uint32_t q = t0 + tid; q < t1; q += HEAVY_THREADS) acc.add(Acc30<F30>::load_raw(partials[q]));
         __syncthreads();  // previous iteration's readers are done with sh / partials[t0]
-        sh[tid] = acc.to_packed();
+        acc.store_raw(&sh[tid]);
         __syncthreads();
         for (uint32_t d = HEAVY_THREADS / 2; d > 0; d >>= 1) {
             if (tid < d) {
-                Acc30<F30> x = Acc30<F30>::from_packed(sh[tid]);
-                x.add(Acc30<F30>::from_packed(sh[tid + d]));
-                sh[tid] = x.to_packed();
+                Acc30<F30> x = Acc30<F30>::load_raw(sh[tid]);
+                x.add(Acc30<F30>::load_raw(sh[tid + d]));
+                x.store_raw(&sh[tid]);
             }
             __syncthreads();
         }
@@ -370,9 +363,9 @@ __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(XYZZ<typena
 // 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
 // ---------------------------------------------------------------------------------------------
 template <class F30>
-__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const XYZZ<typename F30::Std>* __restrict__ partials,
-                                                                    const uint32_t* __restrict__ task_off, uint32_t B, int W,
-                                                                    uint32_t G, XYZZ<typename F30::Std>* __restrict__ chunk_out) {
+__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw<F30>* __restrict__ partials,
+                                                                    const uint32_t* __restrict__ slot_off, uint32_t B, int W, uint32_t G,
+                                                                    AccRaw<F30>* __restrict__ chunk_out) {
     const uint32_t cpw = B / G;
     const uint32_t t = blockIdx.x * RED_THREADS + threadIdx.x;
     if (t >= cpw * (uint32_t)W) return;
@@ -380,35 +373,37 @@ __global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const XYZZ<t
     Acc30<F30> run = Acc30<F30>::identity(), tot = Acc30<F30>::identity();
     for (uint32_t bb = G; bb-- > 0;) {
         const uint32_t gb = w * B + b_lo + bb;
-        const uint32_t t0 = task_off[gb], t1 = task_off[gb + 1];
-        if (t1 > t0) run.add(Acc30<F30>::from_packed(partials[t0]));  // multi-task buckets were pre-combined into [t0]
+        const uint32_t t0 = slot_off[gb];
+        uint32_t np = slot_off[gb + 1] - t0;
+        if (np > HEAVY_PARTS) np = 1;  // pre-combined into [t0] by heavy_reduce_kernel
+        for (uint32_t q = 0; q < np; ++q) run.add(Acc30<F30>::load_raw(partials[t0 + q]));
         tot.add(run);
     }
     // sum_b (b+1) S_b over the chunk = tot + b_lo * run
     if (b_lo) tot.add(run.mul_small(b_lo));
-    chunk_out[t] = tot.to_packed();
+    tot.store_raw(&chunk_out[t]);
 }
 
 template <class F30>
-__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const XYZZ<typename F30::Std>* __restrict__ chunk_out, uint32_t cpw,
+__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw<F30>* __restrict__ chunk_out, uint32_t cpw,
                                                                     XYZZ<typename F30::Std>* __restrict__ window_sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    XYZZ<typename F30::Std>* sh = reinterpret_cast<XYZZ<typename F30::Std>*>(smem);
+    AccRaw<F30>* sh = reinterpret_cast<AccRaw<F30>*>(smem);
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     Acc30<F30> acc = Acc30<F30>::identity();
-    for (uint32_t j = tid; j < cpw; j += WIN_THREADS) acc.add(Acc30<F30>::from_packed(chunk_out[(uint64_t)w * cpw + j]));
-    sh[tid] = acc.to_packed();
+    for (uint32_t j = tid; j < cpw; j += WIN_THREADS) acc.add(Acc30<F30>::load_raw(chunk_out[(uint64_t)w * cpw + j]));
+    acc.store_raw(&sh[tid]);
     __syncthreads();
     for (uint32_t d = WIN_THREADS / 2; d > 0; d >>= 1) {
         if (tid < d) {
-            Acc30<F30> x = Acc30<F30>::from_packed(sh[tid]);
-            x.add(Acc30<F30>::from_packed(sh[tid + d]));
-            sh[tid] = x.to_packed();
+            Acc30<F30> x = Acc30<F30>::load_raw(sh[tid]);
+            x.add(Acc30<F30>::load_raw(sh[tid + d]));
+            x.store_raw(&sh[tid]);
         }
         __syncthreads();
     }
     // the W window sums are what leaves the device: standard arkworks Montgomery radix
-    if (tid == 0) window_sums[w] = Acc30<F30>::from_packed(sh[0]).to_std();
+    if (tid == 0) window_sums[w] = Acc30<F30>::load_raw(sh[0]).to_std();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,10 +466,10 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
     plan->c = c;
     plan->W = W;
     plan->B = 1u << (c - 1);
-    // task granularity: ~2x the mean bucket load, power of two, >= 32
-    uint64_t mean = n / plan->B + 1;
-    uint32_t l = 32;
-    while (l < 2 * mean && l < (1u << 20)) l <<= 1;
+    // segment length of the bucket pass: 128 entries per lane, shorter for small inputs so that the pass still has
+    // >= ~4 segments per lane slot of the chip (256 CUs x 4 SIMDs x 2 waves x 64 lanes)
+    uint32_t l = 128;
+    while (l > 16 && (n * (uint64_t)plan->W) / l < 4ull * 131072ull) l >>= 1;
     plan->Lmax = l;
     // histogram / scatter chunking: ~2048 workgroups in total, chunk a multiple of 1024 points
     uint64_t nchunks = 2048 / (uint64_t)plan->W;
@@ -502,15 +497,17 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
     const uint64_t nw = n * (uint64_t)plan.W;
     if (nw >= ((uint64_t)1 << 32)) return G16_ERR_BAD_LENGTH;
     uint16_t* planes = nullptr;
-    uint32_t *counts = nullptr, *cursor = nullptr;
+    uint32_t *counts = nullptr, *cursor = nullptr, *nparts = nullptr, *block_sums = nullptr;
     G16_TRY(arena.alloc_n(nw ? nw : 1, &planes));
     G16_TRY(arena.alloc_n((size_t)3 * M + 1, &counts));  // counts | scatter cursors | heavy count + list
     cursor = counts + M;
     out->heavy = counts + 2 * (size_t)M;
     G16_TRY(arena.alloc_n((size_t)M + 1, &out->offsets));
     G16_TRY(arena.alloc_n((size_t)M + 1, &out->task_off));
+    G16_TRY(arena.alloc_n((size_t)M, &nparts));
     G16_TRY(arena.alloc_n(nw ? nw : 1, &out->sorted));
-    out->max_tasks = (uint32_t)(nw / plan.Lmax) + M;
+    out->max_segments = (uint32_t)((nw + plan.Lmax - 1) / plan.Lmax);
+    out->max_tasks = out->max_segments + M;   // a bucket gets one slot per segment it touches: <= segments + buckets in total
     G16_HIP_TRY(hipMemsetAsync(counts, 0, ((size_t)2 * M + 1) * sizeof(uint32_t), st));
     PlanDev pd;
     pd.c = plan.c; pd.W = plan.W; pd.B = plan.B;
@@ -524,28 +521,30 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
                                         128 * 1024));
         attr_set = true;
     }
+    const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
     if (n) {
         hipLaunchKernelGGL((digits_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pd, planes);
         G16_LAUNCH_CHECK();
-        const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
         hipLaunchKernelGGL(bucket_count_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
                            counts);
         G16_LAUNCH_CHECK();
     }
-    {
-        const uint32_t nblocks = (M + SCAN_TILE - 1) / SCAN_TILE, lml = (uint32_t)ilog2(plan.Lmax);
-        uint32_t* block_sums = nullptr;
-        G16_TRY(arena.alloc_n((size_t)2 * nblocks, &block_sums));
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, counts, M, lml, block_sums);
+    const uint32_t nblocks = (M + SCAN_TILE - 1) / SCAN_TILE, lseg_log = (uint32_t)ilog2(plan.Lmax);
+    G16_TRY(arena.alloc_n((size_t)nblocks, &block_sums));
+    auto prefix_scan = [&](const uint32_t* vals, uint32_t* prefix) -> int {
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, M, block_sums);
         G16_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nblocks, M, out->offsets, out->task_off);
+        hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nblocks, M, prefix);
         G16_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, counts, M, lml, block_sums, out->offsets, out->task_off,
-                           out->heavy);
+        hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, M, block_sums, prefix);
         G16_LAUNCH_CHECK();
-    }
+        return G16_OK;
+    };
+    G16_TRY(prefix_scan(counts, out->offsets));
+    hipLaunchKernelGGL(bucket_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, out->offsets, M, lseg_log, nparts, out->heavy);
+    G16_LAUNCH_CHECK();
+    G16_TRY(prefix_scan(nparts, out->task_off));
     if (n) {
-        const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
                            out->offsets, cursor, out->sorted);
         G16_LAUNCH_CHECK();
@@ -557,18 +556,22 @@ template <class F>
 int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena, hipStream_t st,
                     MsmBuffers<F>* out, EventTimer* bucket_timer) {
     typedef typename Lazy30<F>::acc_type F30;
+    typedef AccRaw<typename Lazy30<F>::type> Raw;
     const MsmPlan& plan = ss.plan;
     const uint32_t M = plan.B * (uint32_t)plan.W;
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
-    G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &out->partials));
-    G16_TRY(arena.alloc_n((size_t)cpw * plan.W, &out->chunk_out));
+    Raw *partials = nullptr, *chunk_out = nullptr;
+    G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
+    G16_TRY(arena.alloc_n((size_t)cpw * plan.W, &chunk_out));
     G16_TRY(arena.alloc_n((size_t)plan.W, &out->window_sums));
+    out->partials = partials;
+    out->chunk_out = chunk_out;
     if (bucket_timer) G16_TRY(bucket_timer->start(st));
-    if (ss.max_tasks) {
-        const uint64_t lanes = (uint64_t)ss.max_tasks * F30::LANES_PER_TASK;
+    if (ss.max_segments) {
+        const uint64_t lanes = (uint64_t)ss.max_segments * F30::LANES_PER_TASK;
         hipLaunchKernelGGL((bucket_accumulate30_kernel<F30>), dim3((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
-                           st, d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), out->partials);
+                           st, d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), partials);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));
@@ -578,11 +581,12 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
 template <class F>
 int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     typedef typename Lazy30<F>::type F30;
+    typedef AccRaw<F30> Raw;
     const MsmPlan& plan = ss.plan;
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
     static bool attr_set = false;
-    const size_t lds_heavy = sizeof(XYZZ<F>) * HEAVY_THREADS, lds_win = sizeof(XYZZ<F>) * WIN_THREADS;
+    const size_t lds_heavy = sizeof(Raw) * HEAVY_THREADS, lds_win = sizeof(Raw) * WIN_THREADS;
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&heavy_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_heavy));
@@ -590,12 +594,14 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
                                         (int)lds_win));
         attr_set = true;
     }
-    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, buf.partials, ss.task_off, ss.heavy);
+    Raw* partials = static_cast<Raw*>(buf.partials);
+    Raw* chunk_out = static_cast<Raw*>(buf.chunk_out);
+    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, partials, ss.task_off, ss.heavy);
     G16_LAUNCH_CHECK();
-    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, buf.partials,
-                       ss.task_off, plan.B, plan.W, G, buf.chunk_out);
+    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, partials,
+                       ss.task_off, plan.B, plan.W, G, chunk_out);
     G16_LAUNCH_CHECK();
-    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.W), dim3(WIN_THREADS), lds_win, st, buf.chunk_out, cpw, buf.window_sums);
+    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.W), dim3(WIN_THREADS), lds_win, st, chunk_out, cpw, buf.window_sums);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
