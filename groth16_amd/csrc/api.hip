@@ -263,28 +263,37 @@ struct Impl {
         G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));
 
         // ---- witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it.
-        // Whole key on this GPU: it runs on stream 2 underneath the (much longer) bucket passes.  Sharded key (this rank
-        // holds < 1/3 of the bases, but the witness map is replicated at full size): the bucket passes are too short to
-        // hide it and their long-lived waves would starve it, so it goes first, alone, on stream 1.
+        // Whole key on this GPU: it runs on stream 2 underneath the (much longer) bucket passes, and is released only once
+        // the witness digit/sort pass has finished, so that the first bucket pass starts as early as possible.
+        // Sharded key (this rank holds < 1/3 of the bases, but the witness map is replicated at full size): the bucket
+        // passes are too short to hide it and their long-lived waves would starve it, so it goes first, alone, on stream 1.
         Fr* d_h = nullptr;
         G16_TRY(ctx->arena.alloc_n(n, &d_h));
         const bool sharded = pk->a_count * 3 < m;
         hipStream_t s_wm = sharded ? s1 : s2;
-        if (!sharded) G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
-        G16_TRY(ctx->t_wm.start(s_wm));
-        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s_wm)));
-        G16_TRY(ctx->t_wm.stop(s_wm));
-        // h's digit/sort pass follows on the same stream, so that the h bucket pass can start the moment stream 1 is free
         ScalarSort sort_h, sort_z, sort_l;
-        G16_TRY(ctx->t_prep_h.start(s_wm));
-        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, s_wm, &sort_h)));
-        G16_TRY(ctx->t_prep_h.stop(s_wm));
-        G16_HIP_TRY(hipEventRecord(ctx->ev_h, s_wm));
+        auto enqueue_witness_map = [&]() -> int {
+            G16_TRY(ctx->t_wm.start(s_wm));
+            G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s_wm)));
+            G16_TRY(ctx->t_wm.stop(s_wm));
+            // h's digit/sort pass follows on the same stream, so that the h bucket pass can start the moment stream 1 is free
+            G16_TRY(ctx->t_prep_h.start(s_wm));
+            G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, s_wm, &sort_h)));
+            G16_TRY(ctx->t_prep_h.stop(s_wm));
+            G16_HIP_TRY(hipEventRecord(ctx->ev_h, s_wm));
+            return G16_OK;
+        };
+        if (sharded) G16_TRY(enqueue_witness_map());
 
         // ---- stream 1: assignment = full_assignment[1..] (prover.rs:80-85): ONE digit/sort pass for a, b_g1, b_g2 (and l)
         G16_TRY(ctx->t_prep_z.start(s1));
         G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, ctx->arena, s1, &sort_z)));
         G16_TRY(ctx->t_prep_z.stop(s1));
+        if (!sharded) {
+            G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));   // (re-recorded: now also covers the witness sort)
+            G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
+            G16_TRY(enqueue_witness_map());
+        }
 
         MsmBuffers<Fq> buf_h, buf_l, buf_a, buf_b1;
         MsmBuffers<Fq2> buf_b2;
@@ -652,205 +661,6 @@ struct Impl {
         memcpy(out, &res, sizeof(A));
         return G16_OK;
     }
-    // ---------------------------------------------------------------------------------------
-    // randomized CPU self-test of the 30-bit lazy arithmetic (fp30.hpp) against the standard field
-    // and group code; returns 0 or the number of the first failing check
-    static uint64_t sm_next(uint64_t& s) {
-        s += 0x9E3779B97F4A7C15ULL;
-        uint64_t z = s;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-        return z ^ (z >> 31);
-    }
-    static Fq rand_fq(uint64_t& st) {
-        Fq acc = Fq::zero();
-        const Fq two64 = Fq::from_u64(1ULL << 32).sqr();
-        for (int k = 0; k < 8; ++k) acc = acc * two64 + Fq::from_u64(sm_next(st));
-        return acc;
-    }
-    typedef Fp30<typename Fq::Params> F30;
-    static F30 to30(const Fq& x) { const Fq t = F30::std_to_r30(x); return F30::unpack(t.v); }
-    static int selftest30(uint64_t seed, int iters) {
-        uint64_t st = seed;
-        for (int it = 0; it < iters; ++it) {
-            Fq x = rand_fq(st), y = rand_fq(st);
-            if (it == 0) { x = Fq::zero(); }
-            if (it == 1) { x = Fq::zero() - Fq::one(); y = x; }
-            if (it == 2) { x = Fq::one(); }
-            const F30 a = to30(x), b = to30(y);
-            {   // pack/unpack round trip
-                Fq t = F30::std_to_r30(x), u;
-                F30::unpack(t.v).pack(u.v);
-                if (!(t == u)) return 1;
-            }
-            if (!(a.mul(b).to_std() == x * y)) return 2;
-            if (!(a.add(b).to_std() == x + y)) return 3;
-            if (!(a.template sub<2>(b).to_std() == x - y)) return 4;
-            if (!(a.template sub<8>(b).to_std() == x - y)) return 5;
-            if (!(a.neg2().to_std() == x.neg())) return 6;
-            // lazy chains: products of loosely reduced operands (< 16p)
-            const F30 big1 = a.add(b).add(a).template sub<8>(b);        // 2a, bound < 12p
-            const F30 big2 = b.template sub<8>(a).add(b);               // 2b - a, bound < 11p
-            if (!(big1.mul(big2).to_std() == (x + x) * (y + y - x))) return 7;
-            if (!(big1.sqr().to_std() == (x + x).sqr())) return 8;
-            // zero tests
-            const F30 z0 = a.template sub<8>(a);                          // == 8p
-            if (!z0.maybe_zero() || !z0.is_zero_exact()) return 9;
-            const F30 nz = a.template sub<8>(a).add(F30::one());
-            if (nz.is_zero_exact()) return 10;
-            if (a.is_zero_exact() != x.is_zero()) return 11;
-        }
-        // accumulator against the generic XYZZ code, including doubling and cancellation
-        const G1A gen = C::g1_generator();
-        std::vector<G1A> pts;
-        G1X run = G1X::from_affine(gen);
-        for (int i = 0; i < 24; ++i) {
-            uint32_t k[2] = {(uint32_t)sm_next(st) | 1u, 0};
-            pts.push_back(run.mul_bits(k, 32).to_affine());
-            run.add_affine(gen);
-        }
-        for (int round = 0; round < 4; ++round) {
-            std::vector<G1A> seq;
-            for (int i = 0; i < 40; ++i) seq.push_back(pts[sm_next(st) % pts.size()]);
-            if (round == 1) { seq[1] = seq[0]; }                          // P + P -> doubling branch
-            if (round == 2) { seq[1] = seq[0].neg(); }                    // P - P -> identity, then keep adding
-            if (round == 3) { seq[3] = seq[0]; seq[2] = seq[1]; seq[5] = seq[4].neg(); }
-            Acc30<F30> acc = Acc30<F30>::identity();
-            G1X ref = G1X::identity();
-            for (size_t i = 0; i < seq.size(); ++i) {
-                acc.add_affine(to30(seq[i].x), to30(seq[i].y));
-                ref.add_affine(seq[i]);
-                const G1A got = acc.to_std().to_affine(), want = ref.to_affine();
-                if (!(got == want)) return 100 + round * 100 + (int)i;
-            }
-        }
-        // ---- full additions / doublings / small multiples / packed storage of the lazy accumulator (G1)
-        {
-            typedef Acc30<F30> A30;
-            auto lift = [&](const G1X& p) { return A30::from_packed(p.is_identity() ? G1X::identity()
-                                                : G1X{F30::std_to_r30(p.x), F30::std_to_r30(p.y), F30::std_to_r30(p.zz), F30::std_to_r30(p.zzz)}); };
-            for (int it = 0; it < 12; ++it) {
-                G1X a = G1X::identity(), b = G1X::identity();
-                for (int i = 0; i < 3; ++i) { a.add_affine(pts[sm_next(st) % pts.size()]); b.add_affine(pts[sm_next(st) % pts.size()]); }
-                if (it == 1) b = a;
-                if (it == 2) b = a.neg();
-                if (it == 3) b = G1X::identity();
-                if (it == 4) a = G1X::identity();
-                A30 la = lift(a), lb = lift(b);
-                A30 sum = la; sum.add(lb);
-                G1X rs = a; rs.add(b);
-                if (!(sum.to_std().to_affine() == rs.to_affine())) return 40 + it;
-                // storage round trip keeps the group element
-                if (!(A30::from_packed(sum.to_packed()).to_std().to_affine() == rs.to_affine())) return 60 + it;
-                A30 d = la; d.dbl();
-                if (!(d.to_std().to_affine() == a.dbl().to_affine())) return 80 + it;
-                const uint32_t k = (uint32_t)(sm_next(st) % 40000u);
-                uint32_t kw[1] = {k};
-                if (!(la.mul_small(k).to_std().to_affine() == a.mul_bits(kw, 32).to_affine())) return 90;
-                // chained lazy adds (bounds must hold across many operations)
-                A30 chain = la;
-                G1X rchain = a;
-                for (int j = 0; j < 6; ++j) { chain.add(lb); rchain.add(b); chain.add(chain); rchain.add(rchain); }
-                if (!(chain.to_std().to_affine() == rchain.to_affine())) return 95;
-            }
-        }
-        // ---- Fq2 over the 30-bit field, and the G2 accumulator
-        typedef Fp2x30<typename Fq::Params> F230;
-        for (int it = 0; it < iters / 4 + 4; ++it) {
-            Fq2 x = {rand_fq(st), rand_fq(st)}, y = {rand_fq(st), rand_fq(st)};
-            if (it == 0) x = Fq2::zero();
-            if (it == 1) { x = {Fq::zero() - Fq::one(), Fq::zero() - Fq::one()}; y = x; }
-            const F230 a = {to30(x.c0), to30(x.c1)}, b = {to30(y.c0), to30(y.c1)};
-            if (!(a.mul_impl(b).to_std() == x.mul_inlined(y))) return 20;
-            if (!(a.sqr_impl().to_std() == x.sqr_inlined())) return 21;
-            if (!(a.mul(b).to_std() == x * y)) return 22;
-            const F230 big1 = a.add(b).add(a).template sub<8>(b), big2 = b.template sub<8>(a).add(b);  // 2a (<12p), 2b - a (<11p)
-            if (!(big1.mul_impl(big2).to_std() == (x + x) * (y + y - x))) return 23;
-            if (!(big1.sqr_impl().to_std() == (x + x).sqr())) return 24;
-            if (a.is_zero_exact() != x.is_zero()) return 25;
-            if (!a.template sub<8>(a).is_zero_exact()) return 26;
-        }
-        // ---- lane-pair Fq2: the pure per-lane kernels against the one-lane Fq2 product
-        typedef Fp2p30<typename Fq::Params> FP;
-        for (int it = 0; it < iters / 4 + 4; ++it) {
-            Fq2 x = {rand_fq(st), rand_fq(st)}, y = {rand_fq(st), rand_fq(st)};
-            if (it == 0) x = Fq2::zero();
-            if (it == 1) { x = {Fq::zero() - Fq::one(), Fq::zero() - Fq::one()}; y = x; }
-            F30 a0 = to30(x.c0), a1 = to30(x.c1), b0 = to30(y.c0), b1 = to30(y.c1);
-            if (it & 1) {   // loosely reduced operands (< 12p)
-                a0 = a0.add(b0).add(a0).template sub<8>(b0); a1 = a1.add(b1).add(a1).template sub<8>(b1);
-                x = x + x;
-            }
-            const Fq2 want_m = x * y, want_s = x.sqr();
-            if (!(FP::pair_mul(false, a0, a1, b0, b1).to_std() == want_m.c0)) return 36;
-            if (!(FP::pair_mul(true, a1, a0, b1, b0).to_std() == want_m.c1)) return 37;
-            if (!(FP::pair_sqr(false, a0, a1).to_std() == want_s.c0)) return 38;
-            if (!(FP::pair_sqr(true, a1, a0).to_std() == want_s.c1)) return 39;
-        }
-        // ---- the bucket kernel's Karatsuba Fq2 (register-passed products, settled accumulator)
-        typedef Fp2k30<typename Fq::Params> FK;
-        for (int it = 0; it < iters / 4 + 4; ++it) {
-            Fq2 x = {rand_fq(st), rand_fq(st)}, y = {rand_fq(st), rand_fq(st)};
-            if (it == 0) x = Fq2::zero();
-            if (it == 1) { x = {Fq::zero() - Fq::one(), Fq::zero() - Fq::one()}; y = x; }
-            const FK a = {to30(x.c0), to30(x.c1)}, b = {to30(y.c0), to30(y.c1)};
-            if (!(a.mul(b).to_std() == x * y)) return 30;
-            if (!(a.sqr().to_std() == x.sqr())) return 31;
-            const FK big1 = a.add(b).add(a).template sub<8>(b), big2 = b.template sub<8>(a).add(b);  // 2a (<12p), 2b - a (<11p)
-            if (!(big1.mul(big2).to_std() == (x + x) * (y + y - x))) return 32;
-            if (!(big1.sqr().to_std() == (x + x).sqr())) return 33;
-            const FK wide = big1.add(big1).template sub<16>(b);      // 4a - b, bound < 30p
-            if (!(wide.settle().to_std() == (x + x + x + x - y))) return 34;
-            if (!(wide.settle().mul(b).to_std() == (x + x + x + x - y) * y)) return 35;
-        }
-        {
-            const G2A gen2 = C::g2_generator();
-            std::vector<G2A> pts2;
-            G2X run2 = G2X::from_affine(gen2);
-            for (int i = 0; i < 12; ++i) {
-                uint32_t k[2] = {(uint32_t)sm_next(st) | 1u, 0};
-                pts2.push_back(run2.mul_bits(k, 32).to_affine());
-                run2.add_affine(gen2);
-            }
-            for (int round = 0; round < 3; ++round) {
-                std::vector<G2A> seq;
-                for (int i = 0; i < 24; ++i) seq.push_back(pts2[sm_next(st) % pts2.size()]);
-                if (round == 1) { seq[1] = seq[0]; }
-                if (round == 2) { seq[1] = seq[0].neg(); seq[4] = seq[3]; }
-                Acc30<F230> acc = Acc30<F230>::identity();
-                G2X ref = G2X::identity();
-                for (size_t i = 0; i < seq.size(); ++i) {
-                    const F230 px = {to30(seq[i].x.c0), to30(seq[i].x.c1)}, py = {to30(seq[i].y.c0), to30(seq[i].y.c1)};
-                    acc.add_affine(px, py);
-                    ref.add_affine(seq[i]);
-                    if (!(acc.to_std().to_affine() == ref.to_affine())) return 1000 + round * 100 + (int)i;
-                }
-                {   // the same sequence through the Karatsuba accumulator used by the G2 bucket kernel
-                    Acc30<FK> ak = Acc30<FK>::identity();
-                    G2X rk = G2X::identity();
-                    for (size_t i = 0; i < seq.size(); ++i) {
-                        const FK px = {to30(seq[i].x.c0), to30(seq[i].x.c1)};
-                        FK py = {to30(seq[i].y.c0), to30(seq[i].y.c1)};
-                        G2A q = seq[i];
-                        if (i & 1) { py = py.neg2(); q = q.neg(); }
-                        ak.add_affine(px, py);
-                        rk.add_affine(q);
-                        if (!(ak.to_std().to_affine() == rk.to_affine())) return 3000 + round * 100 + (int)i;
-                        if (!(Acc30<FK>::from_packed(ak.to_packed()).to_std().to_affine() == rk.to_affine())) return 3500 + round * 100 + (int)i;
-                    }
-                }
-                // full add / dbl / small multiple on G2
-                Acc30<F230> other = Acc30<F230>::from_packed(acc.to_packed());
-                G2X ro = ref;
-                other.dbl(); ro = ro.dbl();
-                other.add(acc); ro.add(ref);
-                if (!(other.to_std().to_affine() == ro.to_affine())) return 2000 + round;
-                uint32_t kw[1] = {12345u + (uint32_t)round};
-                if (!(acc.mul_small(kw[0]).to_std().to_affine() == ref.mul_bits(kw, 32).to_affine())) return 2100 + round;
-            }
-        }
-        return 0;
-    }
 };
 
 }  // namespace
@@ -1045,12 +855,6 @@ int g16_host_msm_model(int curve, int g2, const uint64_t* bases, const uint64_t*
     if (!out_affine || (n && (!bases || !scalars))) return G16_ERR_BAD_ARG;
     if (!g2) G16_DISPATCH(curve, I::template msm_model<typename I::Fq>(bases, scalars, n, c, out_affine));
     G16_DISPATCH(curve, I::template msm_model<typename I::Fq2>(bases, scalars, n, c, out_affine));
-}
-
-int g16_host_selftest(int curve, uint64_t seed, int iters) {
-    if (curve == G16_BLS12_381) return Impl<Bls12_381>::selftest30(seed, iters);
-    if (curve == G16_BN254) return Impl<Bn254>::selftest30(seed, iters);
-    return -1;
 }
 
 const char* g16_strerror(int status) {

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void digits_kernel(const Fr* __restrict__ scal
 // ---------------------------------------------------------------------------------------------
 // 2. histogram   grid = (chunks, W)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const uint16_t* __restrict__ planes, uint64_t n, uint32_t chunk,
+static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const uint16_t* __restrict__ planes, uint64_t n, uint32_t chunk,
                                                                     int c, uint32_t B, uint32_t* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
@@ -124,7 +124,7 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* sh, ui
     return incl - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ vals, uint32_t M,
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ vals, uint32_t M,
                                                                        uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t sa[SCAN_THREADS];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uin
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_block_offsets_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t M,
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_block_offsets_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t M,
                                                                           uint32_t* __restrict__ prefix) {
     __shared__ uint32_t sa[SCAN_THREADS];
     uint32_t carry = 0;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_offsets_kernel(uint32
     if (threadIdx.x == 0) prefix[M] = carry;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const uint32_t* __restrict__ vals, uint32_t M,
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const uint32_t* __restrict__ vals, uint32_t M,
                                                                   const uint32_t* __restrict__ block_base, uint32_t* __restrict__ prefix) {
     __shared__ uint32_t sa[SCAN_THREADS];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const uint32_t
 }
 
 // partial-sum slots of bucket b = number of length-L segments of the sorted list its entries touch
-__global__ void bucket_slots_kernel(const uint32_t* __restrict__ offsets, uint32_t M, uint32_t lseg_log, uint32_t* __restrict__ nparts,
+static __global__ void bucket_slots_kernel(const uint32_t* __restrict__ offsets, uint32_t M, uint32_t lseg_log, uint32_t* __restrict__ nparts,
                                     uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= M) return;
@@ -175,7 +175,7 @@ __global__ void bucket_slots_kernel(const uint32_t* __restrict__ offsets, uint32
 // ---------------------------------------------------------------------------------------------
 // 4. scatter   grid = (chunks, W)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(const uint16_t* __restrict__ planes, uint64_t n, uint32_t chunk,
+static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(const uint16_t* __restrict__ planes, uint64_t n, uint32_t chunk,
                                                                       int c, uint32_t B, const uint32_t* __restrict__ offsets,
                                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -409,6 +409,12 @@ __global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// This file is compiled twice (G16_MSM_PART = 0: BLS12-381 + the curve-independent host helpers, 1: BN254) so that the
+// two sets of template instantiations build in parallel.
+#ifndef G16_MSM_PART
+#define G16_MSM_PART 0
+#endif
+#if G16_MSM_PART == 0
 int msm_window_override() {
     const char* e = getenv("G16_MSM_WINDOW");
     return e ? atoi(e) : 0;
@@ -480,6 +486,8 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
     plan->chunk = (uint32_t)chunk;
     return G16_OK;
 }
+
+#endif  // G16_MSM_PART == 0
 
 static int ilog2(uint32_t v) { int l = 0; while ((1u << l) < v) ++l; return l; }
 
@@ -637,7 +645,10 @@ XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
     template XYZZ<typename C::Fq> fold_windows<typename C::Fq>(const XYZZ<typename C::Fq>*, const MsmPlan&);               \
     template XYZZ<typename C::Fq2> fold_windows<typename C::Fq2>(const XYZZ<typename C::Fq2>*, const MsmPlan&);
 
+#if G16_MSM_PART == 0
 G16_INSTANTIATE_MSM(Bls12_381)
+#else
 G16_INSTANTIATE_MSM(Bn254)
+#endif
 
 }  // namespace g16
