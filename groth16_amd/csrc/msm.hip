@@ -11,23 +11,25 @@
 //   2. bucket_count_kernel  per (point-chunk, window) workgroup: LDS-resident bucket histogram
 //                           (2^(c-1) counters, <= 128 KiB of the 160 KiB LDS) flushed with one
 //                           global atomic per non-empty bucket
-//   3. bucket_scan_kernel   exclusive prefix sums: bucket offsets and task offsets
+//   3. scan_*_kernel, bucket_slots_kernel   prefix sums: bucket offsets, then partial-sum slot offsets
 //   4. bucket_scatter_kernel  same LDS histogram, then one global atomic per bucket reserves a
 //                           slice and LDS atomics hand out the slots: a counting sort of
 //                           (point index | sign) by (window, bucket) -- order inside a bucket is
 //                           irrelevant because group addition commutes
-//   5. bucket_accumulate_kernel  THE hot kernel: one lane per task (a run of <= Lmax sorted
-//                           entries of one bucket) gathers affine bases (96 B / 192 B each)
-//                           and folds them with XYZZ mixed additions (8M+2S, no inversion)
+//   5. bucket_accumulate30_kernel  THE hot kernel: one lane (G1) / lane pair (G2) per 128-entry SEGMENT of the
+//                           sorted list gathers affine bases (96 B / 192 B each) and folds them with XYZZ
+//                           mixed additions (8M+2S, no inversion) in 30-bit lazy arithmetic (fp30.hpp),
+//                           flushing one partial sum per (bucket, segment) it touches
+//   5b. heavy_reduce_kernel cooperative combine of buckets with many partial sums
 //   6. bucket_reduce_kernel / window_reduce_kernel   sum_b (b+1) S_b by chunked running sums
 //   7. host                 sum_w 2^(cw) R_w  (<= 256 doublings)
 //
 // Steps 1-4 depend only on the scalars and are shared by every MSM over the same scalar
 // vector (a_query, b_g1_query, b_g2_query and l_query all use the witness: one sort, four
 // accumulations).
-// Roofline: step 5 reads N*W*(sizeof(Affine)+4) bytes but spends ~10 field products
-// (~3000 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
-// bytes/s it sustains is reported against the 8 TB/s roofline by bench.py regardless.
+// Roofline: step 5 reads ~N*W*(sizeof(Affine)+4) bytes (8.8 GB measured at 2^22, G1) but spends ~10 field
+// products (~3400 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
+// bytes/s it sustains is reported against the 8 TB/s roofline by bench.py regardless (DESIGN.md 4.3).
 #include "internal.hpp"
 #include "msm_common.hpp"
 #include "fp30.hpp"
@@ -207,37 +209,6 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(con
 }
 
 // ---------------------------------------------------------------------------------------------
-// 5. bucket accumulation -- one lane per task
-// ---------------------------------------------------------------------------------------------
-template <class F>
-__global__ __launch_bounds__(ACC_THREADS) void bucket_accumulate_kernel(const Affine<F>* __restrict__ bases, int64_t shift,
-                                                                        uint64_t base_count, const uint32_t* __restrict__ sorted,
-                                                                        const uint32_t* __restrict__ offsets,
-                                                                        const uint32_t* __restrict__ task_off, uint32_t M,
-                                                                        uint32_t lmax_log, XYZZ<F>* __restrict__ partials) {
-    const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
-    const uint32_t ntasks = task_off[M];
-    if (t >= ntasks) return;
-    uint32_t lo = 0, hi = M;  // task_off[lo] <= t < task_off[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (task_off[mid] <= t) lo = mid; else hi = mid;
-    }
-    const uint32_t k = t - task_off[lo];
-    const uint32_t start = offsets[lo] + (k << lmax_log);
-    const uint32_t end = min(offsets[lo + 1], start + (1u << lmax_log));
-    XYZZ<F> acc = XYZZ<F>::identity();
-    for (uint32_t e = start; e < end; ++e) {
-        const uint32_t v = sorted[e];
-        const int64_t idx = (int64_t)(v & 0x7fffffffu) + shift;
-        if (idx < 0 || (uint64_t)idx >= base_count) continue;
-        Affine<F> p = bases[idx];
-        if (v >> 31) p.y = p.y.neg();
-        acc.add_affine(p);
-    }
-    partials[t] = acc;
-}
-
 // 5. bucket accumulation (THE hot kernel), 30-bit lazy arithmetic (fp30.hpp); F30 = Fp30<P> (G1) or Fp2p30<P> (G2, lane pair).
 // Work unit = a SEGMENT of Lseg consecutive entries of the bucket-sorted list, not a bucket: every lane walks exactly
 // Lseg entries, so lanes of a wave finish together whatever the bucket-size distribution (one lane per bucket left ~18 %
