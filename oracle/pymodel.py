@@ -20,6 +20,7 @@ Reference anchors (file:line relative to /root/reference):
   create_proof_with_assignment   src/prover.rs:54-132
   calculate_coeff                src/prover.rs:252-270
   generate_parameters_with_qap   src/generator.rs:47-208
+  prepare_inputs / verify_proof  src/verifier.rs:25-76   (plain Tate pairing)
 External algebra (ark-ff/ec/poly 0.5.0, not vendored) is restated from its published
 definitions: Radix2EvaluationDomain (natural order in/out, ifft scales by 1/n, coset
 fft pre-multiplies coefficient k by g^k), short-Weierstrass a=0 group law.
@@ -878,3 +879,136 @@ def selfcheck() -> None:
 if __name__ == "__main__":
     selfcheck()
     print("pymodel selfcheck OK")
+
+
+# ----------------------------------------------------------------------------------
+# verifier (src/verifier.rs:13-77) -- SURVEY.md row f2.  A deliberately plain reduced Tate pairing
+# e(P, Q) = f_{r,P}(Q)^((q^12-1)/r) over Fq12 = Fq[w]/(w^12 - c6 w^6 - c0): any non-degenerate bilinear pairing
+# decides the Groth16 equation, so this need not be arkworks' optimal ate pairing.  Slow (about a second per pairing).
+# ----------------------------------------------------------------------------------
+
+_TOWER = {
+    # xi = s + u is the sextic non-residue (Fq6 = Fq2[v]/(v^3 - xi), Fq12 = Fq6[w]/(w^2 - v)); w^6 = xi and u^2 = -1 give
+    # (w^6 - s)^2 = -1, i.e. w^12 = 2 s w^6 - (s^2 + 1).  twist: 'M' (b' = b xi, BLS12-381) or 'D' (b' = b / xi, BN254).
+    "bls12_381": dict(s=1, twist="M"),
+    "bn254": dict(s=9, twist="D"),
+}
+
+
+class Fq12:
+    def __init__(self, cp: CurveParams):
+        self.p = cp.q
+        s = _TOWER[cp.name]["s"]
+        self.s = s
+        self.c6 = 2 * s % self.p
+        self.c0 = (-(s * s + 1)) % self.p
+        self.one = [1] + [0] * 11
+        self.zero = [0] * 12
+
+    def add(self, a, b):
+        return [(x + y) % self.p for x, y in zip(a, b)]
+
+    def sub(self, a, b):
+        return [(x - y) % self.p for x, y in zip(a, b)]
+
+    def scale(self, a, k):
+        return [x * k % self.p for x in a]
+
+    def mul(self, a, b):
+        p = self.p
+        t = [0] * 23
+        for i, x in enumerate(a):
+            if x:
+                for j, y in enumerate(b):
+                    t[i + j] += x * y
+        for i in range(22, 11, -1):
+            v = t[i] % p
+            if v:
+                t[i - 6] += self.c6 * v
+                t[i - 12] += self.c0 * v
+        return [x % p for x in t[:12]]
+
+    def pow(self, a, e):
+        r = self.one
+        for bit in bin(e)[2:]:
+            r = self.mul(r, r)
+            if bit == "1":
+                r = self.mul(r, a)
+        return r
+
+    def from_fq2(self, a):  # a0 + a1 u with u = w^6 - s
+        c = [0] * 12
+        c[0] = (a[0] - self.s * a[1]) % self.p
+        c[6] = a[1] % self.p
+        return c
+
+    def inv(self, a):
+        return self.pow(a, self.p ** 12 - 2)
+
+
+def untwist(cp: CurveParams, Q):
+    """G2 affine point over Fq2 -> point of E(Fq12)"""
+    F = Fq12(cp)
+    x, y = F.from_fq2(Q[0]), F.from_fq2(Q[1])
+    w2 = [0, 0, 1] + [0] * 9
+    w3 = [0, 0, 0, 1] + [0] * 8
+    if _TOWER[cp.name]["twist"] == "D":
+        return F.mul(x, w2), F.mul(y, w3)
+    return F.mul(x, F.inv(w2)), F.mul(y, F.inv(w3))
+
+
+def tate_pairing(cp: CurveParams, P, Q):
+    """reduced Tate pairing of P in G1 (affine over Fq) and Q in G2 (affine over Fq2); identity inputs give 1"""
+    F = Fq12(cp)
+    if P is None or Q is None:
+        return F.one
+    p = cp.q
+    xq, yq = untwist(cp, Q)
+    xp, yp = P
+    tx, ty = xp, yp
+    f = F.one
+
+    def line(lam, x0, y0):  # (yQ - y0) - lam (xQ - x0), lam in Fq
+        v = F.sub(yq, F.scale(xq, lam))
+        v[0] = (v[0] + lam * x0 - y0) % p
+        return v
+
+    bits = bin(cp.r)[3:]
+    for i, bit in enumerate(bits):
+        lam = 3 * tx * tx * pow(2 * ty, p - 2, p) % p
+        f = F.mul(F.mul(f, f), line(lam, tx, ty))
+        nx = (lam * lam - 2 * tx) % p
+        ty = (lam * (tx - nx) - ty) % p
+        tx = nx
+        if bit == "1":
+            if tx == xp:  # T = -P at the very last step: vertical line, killed by the final exponentiation
+                assert (ty + yp) % p == 0 and i == len(bits) - 1
+                continue
+            lam = (yp - ty) * pow((xp - tx) % p, p - 2, p) % p
+            f = F.mul(f, line(lam, tx, ty))
+            nx = (lam * lam - tx - xp) % p
+            ty = (lam * (tx - nx) - ty) % p
+            tx = nx
+    return F.pow(f, (p ** 12 - 1) // cp.r)
+
+
+def prepare_inputs(cp: CurveParams, gamma_abc_g1, public_inputs):
+    # src/verifier.rs:25-39
+    if len(public_inputs) + 1 != len(gamma_abc_g1):
+        raise ValueError("MalformedVerifyingKey")
+    G1, _ = groups(cp)
+    acc = gamma_abc_g1[0]
+    for x, b in zip(public_inputs, gamma_abc_g1[1:]):
+        acc = G1.add(acc, G1.mul(b, x))
+    return acc
+
+
+def verify_proof(cp: CurveParams, pk: ProvingKey, proof: Proof, public_inputs) -> bool:
+    """src/verifier.rs:44-76: e(A,B) e(IC,-gamma) e(C,-delta) == e(alpha, beta), on the vk carried by `pk`"""
+    G1, _ = groups(cp)
+    F = Fq12(cp)
+    ic = prepare_inputs(cp, pk.gamma_abc_g1, public_inputs)
+    lhs = tate_pairing(cp, proof.a, proof.b)
+    lhs = F.mul(lhs, tate_pairing(cp, G1.neg(ic), pk.gamma_g2))
+    lhs = F.mul(lhs, tate_pairing(cp, G1.neg(proof.c), pk.delta_g2))
+    return lhs == tate_pairing(cp, pk.alpha_g1, pk.beta_g2)
