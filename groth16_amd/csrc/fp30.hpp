@@ -84,6 +84,13 @@ struct Fp30 {
         r.normalize();
         return r;
     }
+    // a + 2^(k+1) p - b  with the redundant constant selected at run time (scalar fields only; NTT butterflies)
+    G16_HD Fp30 sub_pow2(const Fp30& b, int k) const {
+        Fp30 r;
+        G16_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = l[i] + P::kp_pow2(k, i) - b.l[i];
+        r.normalize();
+        return r;
+    }
     // 2p - a, for a <= 2p (used on canonical inputs)
     G16_HD Fp30 neg2() const { return zero().template sub<2>(*this); }
     // 16p - a, for a < 16p

@@ -82,6 +82,12 @@ def field_struct(name, p):
         out.append("        constexpr uint32_t t[NL30] = %s;" % arr(vals))
         out.append("        return t[i];")
         out.append("    }")
+    # redundant 2^(k+1) * p for k = 0..11 (lazy DIF butterflies subtract operands that double every stage)
+    if name.endswith("FrP"):   # scalar fields only (the NTT); their top limb has room for 4096 p
+        out.append("    G16_HD static constexpr uint32_t kp_pow2(int k, int i) {")
+        out.append("        constexpr uint32_t t[12][NL30] = {%s};" % ", ".join(arr(redundant(2 << k)) for k in range(12)))
+        out.append("        return t[k][i];")
+        out.append("    }")
     # 2^(30 NL) mod p as a plain integer in 32-bit limbs: std-Montgomery multiplying x*R by it gives x*R' mod p
     out.append("    G16_HD static constexpr uint32_t r30_plain(int i) {")
     out.append("        constexpr uint32_t t[N] = %s;" % arr(limbs32(R30 % p, n)))

@@ -35,8 +35,61 @@ struct SelfTest {
     }
     typedef Fp30<typename Fq::Params> F30;
     static F30 to30(const Fq& x) { const Fq t = F30::std_to_r30(x); return F30::unpack(t.v); }
+    // scalar field in the 30-bit form (NTT butterflies): products against w*R' tables, lazy DIT / DIF butterflies
+    static Fr rand_fr(uint64_t& st) {
+        Fr acc = Fr::zero();
+        const Fr two64 = Fr::from_u64(1ULL << 32).sqr();
+        for (int k = 0; k < 8; ++k) acc = acc * two64 + Fr::from_u64(sm_next(st));
+        return acc;
+    }
+    static int selftest_fr30(uint64_t seed, int iters) {
+        typedef Fp30<typename Fr::Params> R30;
+        uint64_t st = seed ^ 0xF7;
+        for (int it = 0; it < iters; ++it) {
+            Fr x = rand_fr(st), y = rand_fr(st), w = rand_fr(st);
+            if (it == 0) { x = Fr::zero(); }
+            if (it == 1) { x = Fr::zero() - Fr::one(); y = x; w = x; }
+            // data stays in the standard form x*R; tables are w*R'
+            const R30 a = R30::unpack(x.v), b = R30::unpack(y.v);
+            const Fr wt = R30::std_to_r30(w);
+            const R30 w30 = R30::unpack(wt.v);
+            auto canon = [](const R30& v) { Fr o; v.mul_impl(R30::one()).canonical_lt2p().pack(o.v); return o; };
+            if (!(canon(a.mul_impl(w30)) == x * w)) return 501;
+            // DIT butterfly chain: 11 stages without reduction
+            R30 u = a, v = b;
+            Fr ru = x, rv = y;
+            for (int k = 0; k < 11; ++k) {
+                const R30 t = v.mul_impl(w30);
+                const R30 nu = u.add(t), nv = u.template sub<2>(t);
+                const Fr rt = rv * w;
+                const Fr rnu = ru + rt, rnv = ru - rt;
+                u = nu; v = nv; ru = rnu; rv = rnv;
+            }
+            if (!(canon(u) == ru) || !(canon(v) == rv)) return 502;
+            // DIF butterfly chain: sums double every stage, subtraction adds 2^(k+1) p
+            u = a; v = b; ru = x; rv = y;
+            R30 s2 = a, d2 = b;
+            for (int k = 0; k < 11; ++k) {
+                const R30 nu = u.add(v);
+                const R30 nv = u.sub_pow2(v, k).mul_impl(w30);
+                const Fr rnu = ru + rv, rnv = (ru - rv) * w;
+                // keep BOTH operands on the doubling lineage for the next stage (worst case for the bounds)
+                s2 = nu; d2 = nv;
+                u = nu; v = nu.add(nv).sub_pow2(nv, k + 1 < 12 ? k + 1 : 11);   // = nu, but with a grown bound
+                ru = rnu; rv = rnu;
+                if (!(canon(d2) == rnv)) return 503;
+            }
+            if (!(canon(s2) == ru)) return 504;
+        }
+        return 0;
+    }
+
     static int selftest30(uint64_t seed, int iters) {
         uint64_t st = seed;
+        {
+            const int rc = selftest_fr30(seed, iters);
+            if (rc) return rc;
+        }
         for (int it = 0; it < iters; ++it) {
             Fq x = rand_fq(st), y = rand_fq(st);
             if (it == 0) { x = Fq::zero(); }

@@ -3,29 +3,44 @@
 // Replaces ark-poly's Radix2EvaluationDomain::{fft,ifft}_in_place and the coset variants as
 // called from /root/reference/src/r1cs_to_qap.rs:201-207,220-221,232.
 //
-// Shape: an n-point transform is split into passes; each pass loads a tile of 2^11 elements
-// (64 KiB) into LDS, runs up to 11 butterfly stages there and writes the tile back, so one
-// NTT is ceil(log2 n / ~8) sweeps over HBM instead of log2 n.  The last/first pass works on
-// contiguous tiles; the others gather 2^T-element runs (>= 1 KiB contiguous for T >= 5) so
-// that every wave-level access is a full-line access.  Decimation-in-frequency (natural ->
-// bit-reversed) is paired with decimation-in-time (bit-reversed -> natural) so the witness map
-// never needs a separate bit-reversal between its inverse and forward transforms; the coset
-// shift g^k and the 1/n factor ride along as a pre-scale on the DIT load.
-// Bound: HBM bandwidth (2*32*n bytes per sweep) with the Fr Montgomery product
-// (8 limbs, 136 v_mad_u64_u32) as the competing VALU term; no MFMA (integer modular work).
+// Shape: an n-point transform is split into passes; each pass stages a tile of 2^11 elements in LDS,
+// runs up to 11 butterfly stages there and writes the tile back, so one NTT is ceil(log2 n / ~8) sweeps
+// over HBM instead of log2 n.  The last/first pass works on contiguous tiles; the others gather
+// 2^T-element runs (>= 1 KiB contiguous for T >= 5) so that every wave-level access is a full-line access.
+// Inside a pass the stages are taken three at a time: a lane pulls 8 elements out of LDS, does 12
+// butterflies in registers (radix-8 block) and puts them back -- 4 LDS round trips for 11 stages.
+// The tile is kept as structure-of-arrays of 30-bit limbs ([9][2048+pad] words, 76 KB): consecutive lanes
+// touch consecutive words, and one pad word per 32 elements breaks the stride-8 pattern of the first round.
+//
+// Arithmetic: Fr in the 30-bit lazy representation of fp30.hpp (9 limbs; a product is 162 carry-free
+// v_mad_u64_u32).  Data stays in the arkworks Montgomery form (x*R); the twiddle / scale tables are stored as
+// w*R' (R' = 2^270), so mont30(x*R, w*R') = x*w*R and no conversion of the data is ever needed.  Butterfly
+// outputs are left loosely reduced for the whole pass (DIT: sums grow by <= 2p per stage; DIF: sums double per
+// stage and the subtraction adds the matching redundant 2^(k+1) p) and canonicalised once, by a product with
+// R' mod p, when the tile is written back.
+// Decimation-in-frequency (natural -> bit-reversed) is paired with decimation-in-time (bit-reversed ->
+// natural) so the witness map never needs a separate bit-reversal between its inverse and forward transforms;
+// the coset shift g^k and the 1/n factor ride along as a pre-scale on the DIT load.
+// Bound: nominally HBM (2*32*n bytes per sweep); in practice the 46 M Fr products of a 2^22-point transform
+// (VALU) dominate -- see DESIGN.md 4.2.  No MFMA (integer modular work).
 #include "internal.hpp"
+#include "fp30.hpp"
 
 namespace g16 {
 
-static constexpr int NTT_TILE_LOG = 11;   // 2^11 Fr = 64 KiB of LDS per workgroup
+static constexpr int NTT_TILE_LOG = 11;
+static constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
 static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_ROW = NTT_TILE + NTT_TILE / 32;  // padded row length (words) of one limb plane
 
 template <class Fr>
 struct PowTable { Fr p[32]; };  // base^(2^j)
 
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+__device__ __forceinline__ uint32_t lds_col(uint32_t e) { return e + (e >> 5); }
 
-// out[i] = scale * base^e(i),  e(i) = bitrev(i) if rev else i
+// out[i] = scale * base^e(i),  e(i) = bitrev(i) if rev else i     (standard Montgomery arithmetic; `scale` may
+// carry the R'/R factor that turns the table into the w*R' form the 30-bit butterflies consume)
 template <class Fr>
 __global__ void gen_powers_kernel(Fr* __restrict__ out, size_t n, PowTable<Fr> tab, Fr scale, int rev_bits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,13 +53,64 @@ __global__ void gen_powers_kernel(Fr* __restrict__ out, size_t n, PowTable<Fr> t
     out[i] = acc;
 }
 
+// R stages (a radix-2^R block) on every group of 2^R tile elements whose indices differ in the R bits [p0, p0+R):
+// load from the LDS planes, R x 2^(R-1) butterflies in registers, store back.
+template <class P, bool DIT, int R, class GIdx>
+__device__ __forceinline__ void ntt30_round(uint32_t* lds, const Fp<P>* __restrict__ tw, int log_n, int s_lo, int q0, int TT, uint32_t E,
+                                            int done, const GIdx& gidx) {
+    typedef Fp30<P> F;
+    constexpr int NL = F::NL;
+    constexpr int NE = 1 << R;
+    const int p0 = q0 + TT;   // bit position of the round's lowest stage inside the tile index
+    for (uint32_t g = threadIdx.x; g < (E >> R); g += NTT_THREADS) {
+        const uint32_t low = g & ((1u << p0) - 1), high = g >> p0;
+        const uint32_t ebase = (high << (p0 + R)) | low;
+        F x[NE];
+        G16_UNROLL for (int j = 0; j < NE; ++j) {
+            const uint32_t c = lds_col(ebase | ((uint32_t)j << p0));
+            G16_UNROLL for (int l = 0; l < NL; ++l) x[j].l[l] = lds[l * NTT_ROW + c];
+        }
+        const uint64_t gbase = gidx(ebase);  // global index of element 0 of the group (the R varying bits are zero there)
+        G16_UNROLL for (int qq = 0; qq < R; ++qq) {
+            const int q = DIT ? qq : (R - 1 - qq);   // stage inside the round
+            const int s = s_lo + q0 + q;             // global stage: pairs differ in index bit s
+            const int kdone = done + qq;             // DIF: operands are < 2^kdone * 1.1 p
+            G16_UNROLL for (int j = 0; j < NE; ++j) {
+                if (!((j >> q) & 1)) {
+                    const int j2 = j | (1 << q);
+                    // twiddle exponent = (global index of the lower element) mod 2^s, scaled to the n/2-entry table
+                    const uint64_t gi = gbase + ((uint64_t)j << (s_lo + q0));
+                    const uint64_t widx = (gi & ((1ull << s) - 1)) << (log_n - 1 - s);
+                    const F w = F::unpack(tw[widx].v);
+                    if (DIT) {
+                        const F v = x[j2].mul_impl(w);           // < 1.01 p
+                        const F u = x[j];
+                        x[j] = u.add(v);
+                        x[j2] = u.template sub<2>(v);
+                    } else {
+                        const F u = x[j], v = x[j2];
+                        x[j] = u.add(v);
+                        x[j2] = u.sub_pow2(v, kdone).mul_impl(w);
+                    }
+                }
+            }
+        }
+        G16_UNROLL for (int j = 0; j < NE; ++j) {
+            const uint32_t c = lds_col(ebase | ((uint32_t)j << p0));
+            G16_UNROLL for (int l = 0; l < NL; ++l) lds[l * NTT_ROW + c] = x[j].l[l];
+        }
+    }
+}
+
 // One LDS-tiled pass over stages [s_lo, s_hi).  T = log2 of the contiguous run (ignored when s_lo == 0).
-template <class Fr, bool DIT>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(Fr* __restrict__ data, const Fr* __restrict__ tw,
-                                                                const Fr* __restrict__ prescale, int log_n, int s_lo,
-                                                                int s_hi, int T) {
+template <class P, bool DIT>
+__global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(Fp<P>* __restrict__ data, const Fp<P>* __restrict__ tw,
+                                                                 const Fp<P>* __restrict__ prescale, int log_n, int s_lo, int s_hi,
+                                                                 int T) {
+    typedef Fp30<P> F;
+    constexpr int NL = F::NL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Fr* lds = reinterpret_cast<Fr*>(smem);
+    uint32_t* lds = reinterpret_cast<uint32_t*>(smem);  // [NL][NTT_ROW]
     const int K = s_hi - s_lo;
     const int TT = (s_lo == 0) ? 0 : T;
     const uint32_t E = 1u << (K + TT);
@@ -63,52 +129,69 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(Fr* __restrict__ 
         const uint32_t low = e & ((1u << T) - 1), mid = e >> T;
         return base + low + ((uint64_t)mid << s_lo);
     };
+    auto lds_load = [&](uint32_t e) -> F {
+        F x;
+        const uint32_t c = lds_col(e);
+        G16_UNROLL for (int l = 0; l < NL; ++l) x.l[l] = lds[l * NTT_ROW + c];
+        return x;
+    };
+    auto lds_store = [&](uint32_t e, const F& x) {
+        const uint32_t c = lds_col(e);
+        G16_UNROLL for (int l = 0; l < NL; ++l) lds[l * NTT_ROW + c] = x.l[l];
+    };
+    // ---- load the tile (coalesced 32-byte elements), optional pre-scale
     for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
         const uint64_t g = gidx(e);
-        Fr x = data[g];
-        if (prescale) x = x * prescale[g];
-        lds[e] = x;
+        F x = F::unpack(data[g].v);
+        if (prescale) x = x.mul_impl(F::unpack(prescale[g].v));
+        lds_store(e, x);
     }
     __syncthreads();
-    for (int k = 0; k < K; ++k) {
-        const int s = DIT ? (s_lo + k) : (s_hi - 1 - k);
-        const int bitpos = (s - s_lo) + TT;
-        for (uint32_t b = threadIdx.x; b < E / 2; b += NTT_THREADS) {
-            const uint32_t lower = b & ((1u << bitpos) - 1), upper = b >> bitpos;
-            const uint32_t e0 = (upper << (bitpos + 1)) | lower, e1 = e0 | (1u << bitpos);
-            const uint64_t j = gidx(e0) & ((1ull << s) - 1);
-            const Fr w = tw[j << (log_n - 1 - s)];
-            Fr u = lds[e0], v = lds[e1];
-            if (DIT) {
-                v = v * w;
-                lds[e0] = u + v;
-                lds[e1] = u - v;
-            } else {
-                lds[e0] = u + v;
-                lds[e1] = (u - v) * w;
-            }
-        }
+    // ---- stages, three at a time in registers
+    int done = 0;  // stages of this pass already applied (= how often sums may have doubled, DIF)
+    while (done < K) {
+        const int R = (K - done) >= 3 ? 3 : (K - done);
+        const int q0 = DIT ? done : (K - done - R);    // first (lowest) stage of this round, relative to s_lo
+        if (R == 3) ntt30_round<P, DIT, 3>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx);
+        else if (R == 2) ntt30_round<P, DIT, 2>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx);
+        else ntt30_round<P, DIT, 1>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx);
         __syncthreads();
+        done += R;
     }
-    for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) data[gidx(e)] = lds[e];
+    // ---- canonicalise (product with R' mod p brings any loosely reduced value below 1.1 p) and write back
+    for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
+        const F x = lds_load(e).mul_impl(F::one()).canonical_lt2p();
+        Fp<P> o;
+        x.pack(o.v);
+        data[gidx(e)] = o;
+    }
 }
 
-template <class Fr>
-__global__ void bitrev_scale_kernel(Fr* __restrict__ out, const Fr* __restrict__ in, const Fr* __restrict__ table, Fr cst,
+// out[k] = in[bitrev(k)] * table[k] * cst      (table / cst in the w*R' form; either may be absent)
+template <class P>
+__global__ void bitrev_scale_kernel(Fp<P>* __restrict__ out, const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ table, Fp<P> cst,
                                     int has_cst, int log_n) {
+    typedef Fp30<P> F;
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ((size_t)1 << log_n)) return;
-    Fr x = in[bitrev32((uint32_t)k, log_n)];
-    if (table) x = x * table[k];
-    if (has_cst) x = x * cst;
-    out[k] = x;
+    Fp<P> o = in[bitrev32((uint32_t)k, log_n)];
+    if (table || has_cst) {
+        F x = F::unpack(o.v);
+        if (table) x = x.mul_impl(F::unpack(table[k].v));
+        if (has_cst) x = x.mul_impl(F::unpack(cst.v));
+        x.canonical_lt2p().pack(o.v);
+    }
+    out[k] = o;
 }
 
-template <class Fr>
-__global__ void scale_table_kernel(Fr* __restrict__ data, const Fr* __restrict__ table, size_t n) {
+template <class P>
+__global__ void scale_table_kernel(Fp<P>* __restrict__ data, const Fp<P>* __restrict__ table, size_t n) {
+    typedef Fp30<P> F;
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    data[k] = data[k] * table[k];
+    Fp<P> o;
+    F::unpack(data[k].v).mul_impl(F::unpack(table[k].v)).canonical_lt2p().pack(o.v);
+    data[k] = o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -135,46 +218,46 @@ static std::vector<PassPlan> plan_passes(int log_n) {
     return p;
 }
 
-template <class Fr, bool DIT>
-static int launch_pass(Fr* data, const Fr* tw, const Fr* prescale, int log_n, const PassPlan& pp, hipStream_t st) {
+template <class P, bool DIT>
+static int launch_pass(Fp<P>* data, const Fp<P>* tw, const Fp<P>* prescale, int log_n, const PassPlan& pp, hipStream_t st) {
     const int K = pp.s_hi - pp.s_lo;
     const int TT = pp.s_lo == 0 ? 0 : pp.T;
     const size_t E = (size_t)1 << (K + TT);
     const size_t blocks = ((size_t)1 << log_n) / E;
-    const size_t lds_bytes = E * sizeof(Fr);
+    const size_t lds_bytes = (size_t)Fp30<P>::NL * NTT_ROW * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
-        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr, DIT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(Fr) << NTT_TILE_LOG)));
+        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt30_pass_kernel<P, DIT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((ntt_pass_kernel<Fr, DIT>), dim3((unsigned)blocks), dim3(NTT_THREADS), lds_bytes, st, data, tw, prescale,
-                       log_n, pp.s_lo, pp.s_hi, pp.T);
+    hipLaunchKernelGGL((ntt30_pass_kernel<P, DIT>), dim3((unsigned)blocks), dim3(NTT_THREADS), lds_bytes, st, data, tw, prescale, log_n,
+                       pp.s_lo, pp.s_hi, pp.T);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
 
 template <class C>
 int ntt_dif(const Domain<C>* d, typename C::Fr* data, bool inverse, hipStream_t st) {
-    typedef typename C::Fr Fr;
+    typedef typename C::Fr::Params P;
     if (d->log_n == 0) return G16_OK;
     auto passes = plan_passes(d->log_n);
-    const Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
-    for (size_t i = passes.size(); i-- > 0;) G16_TRY((launch_pass<Fr, false>(data, tw, nullptr, d->log_n, passes[i], st)));
+    const typename C::Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
+    for (size_t i = passes.size(); i-- > 0;) G16_TRY((launch_pass<P, false>(data, tw, nullptr, d->log_n, passes[i], st)));
     return G16_OK;
 }
 
 template <class C>
 int ntt_dit(const Domain<C>* d, typename C::Fr* data, bool inverse, const typename C::Fr* prescale, hipStream_t st) {
-    typedef typename C::Fr Fr;
+    typedef typename C::Fr::Params P;
     if (d->log_n == 0) {
         if (prescale) G16_TRY((scale_by_table<C>(data, prescale, 1, st)));
         return G16_OK;
     }
     auto passes = plan_passes(d->log_n);
-    const Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
+    const typename C::Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
     for (size_t i = 0; i < passes.size(); ++i)
-        G16_TRY((launch_pass<Fr, true>(data, tw, i == 0 ? prescale : nullptr, d->log_n, passes[i], st)));
+        G16_TRY((launch_pass<P, true>(data, tw, i == 0 ? prescale : nullptr, d->log_n, passes[i], st)));
     return G16_OK;
 }
 
@@ -183,8 +266,8 @@ int bitrev_scale(const Domain<C>* d, typename C::Fr* out, const typename C::Fr* 
                  const typename C::Fr* cst, hipStream_t st) {
     typedef typename C::Fr Fr;
     const size_t n = d->n;
-    Fr c = cst ? *cst : Fr::one();
-    hipLaunchKernelGGL((bitrev_scale_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, in, table, c,
+    Fr c = cst ? *cst : Fr::zero();
+    hipLaunchKernelGGL((bitrev_scale_kernel<typename Fr::Params>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, in, table, c,
                        cst ? 1 : 0, d->log_n);
     G16_LAUNCH_CHECK();
     return G16_OK;
@@ -193,18 +276,20 @@ int bitrev_scale(const Domain<C>* d, typename C::Fr* out, const typename C::Fr* 
 template <class C>
 int scale_by_table(typename C::Fr* data, const typename C::Fr* table, size_t n, hipStream_t st) {
     typedef typename C::Fr Fr;
-    hipLaunchKernelGGL((scale_table_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, table, n);
+    hipLaunchKernelGGL((scale_table_kernel<typename Fr::Params>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, table, n);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
 
+// table[i] = scale * base^e(i) * R'   (the form the 30-bit kernels multiply by)
 template <class Fr>
-static int gen_powers(Fr* out, size_t n, const Fr& base, const Fr& scale, int rev_bits, hipStream_t st) {
+static int gen_powers30(Fr* out, size_t n, const Fr& base, const Fr& scale, int rev_bits, hipStream_t st) {
     if (n == 0) return G16_OK;
     PowTable<Fr> tab;
     Fr p = base;
     for (int j = 0; j < 32; ++j) { tab.p[j] = p; p = p.sqr(); }
-    hipLaunchKernelGGL((gen_powers_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, tab, scale, rev_bits);
+    const Fr scale30 = Fp30<typename Fr::Params>::std_to_r30(scale);
+    hipLaunchKernelGGL((gen_powers_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, tab, scale30, rev_bits);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
@@ -220,19 +305,20 @@ int domain_create(int log_n, hipStream_t st, Domain<C>** out) {
     Fr omega = C::two_adic_root();
     for (int i = log_n; i < C::TWO_ADICITY; ++i) omega = omega.sqr();
     Fr omega_inv = omega.inverse();
-    d->n_inv = Fr::from_u64((uint64_t)n).inverse();
+    const Fr n_inv = Fr::from_u64((uint64_t)n).inverse();
+    d->n_inv = Fp30<typename Fr::Params>::std_to_r30(n_inv);  // w*R' form, like every table below
     const Fr g = C::fr_generator(), g_inv = C::fr_generator_inv();
-    d->zinv = (g.pow_u64((uint64_t)n) - Fr::one()).inverse();  // 1 / Z(g), r1cs_to_qap.rs:223-226
+    d->zinv = (g.pow_u64((uint64_t)n) - Fr::one()).inverse();  // 1 / Z(g), r1cs_to_qap.rs:223-226 (standard form)
     int rc = G16_OK;
     auto fail = [&](int code) { domain_destroy<C>(d); return code; };
     if (hipMalloc((void**)&d->tw_fwd, half * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->tw_inv, half * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->s1_br, n * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->s2, n * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
-    if ((rc = gen_powers<Fr>(d->tw_fwd, half, omega, Fr::one(), 0, st)) != G16_OK) return fail(rc);
-    if ((rc = gen_powers<Fr>(d->tw_inv, half, omega_inv, Fr::one(), 0, st)) != G16_OK) return fail(rc);
-    if ((rc = gen_powers<Fr>(d->s1_br, n, g, d->n_inv, log_n, st)) != G16_OK) return fail(rc);
-    if ((rc = gen_powers<Fr>(d->s2, n, g_inv, d->n_inv, 0, st)) != G16_OK) return fail(rc);
+    if ((rc = gen_powers30<Fr>(d->tw_fwd, half, omega, Fr::one(), 0, st)) != G16_OK) return fail(rc);
+    if ((rc = gen_powers30<Fr>(d->tw_inv, half, omega_inv, Fr::one(), 0, st)) != G16_OK) return fail(rc);
+    if ((rc = gen_powers30<Fr>(d->s1_br, n, g, n_inv, log_n, st)) != G16_OK) return fail(rc);
+    if ((rc = gen_powers30<Fr>(d->s2, n, g_inv, n_inv, 0, st)) != G16_OK) return fail(rc);
     if (hipStreamSynchronize(st) != hipSuccess) return fail(G16_ERR_HIP);
     *out = d;
     return G16_OK;
@@ -243,7 +329,7 @@ int domain_ensure_gpow(Domain<C>* d, hipStream_t st) {
     typedef typename C::Fr Fr;
     if (d->g_pow) return G16_OK;
     G16_HIP_TRY(hipMalloc((void**)&d->g_pow, d->n * sizeof(Fr)));
-    return gen_powers<Fr>(d->g_pow, d->n, C::fr_generator(), Fr::one(), 0, st);
+    return gen_powers30<Fr>(d->g_pow, d->n, C::fr_generator(), Fr::one(), 0, st);
 }
 
 template <class C>
