@@ -295,7 +295,17 @@ def main():
                 traffic = pt["hbm_bytes_per_launch"]
         except Exception:  # noqa: BLE001
             pass
+        # the bound that actually applies: v_mad_u64_u32 issue.  One G1 mixed addition = 8 products (338
+        # multiply-adds each) + 2 squarings (260); the chip issues at most one v_mad_u64_u32 per ~5 cycles per SIMD
+        # (measured, profiles/r01_ubench.txt): 1024 SIMDs x 64 lanes x 2.4 GHz / 5 = 31.5 T multiply-adds/s.
+        n_windows = 16 if args.log2 >= 16 else None
+        valu = None
+        if n_windows:
+            mads = float(n_pts) * n_windows * (8 * 338 + 2 * 260 if args.curve == "bls12_381" else 8 * 162 + 2 * 126)
+            valu = dict(kind="v_mad_u64_u32 issue (integer VALU)", mads_per_launch=mads, achieved_Tmad_s=mads / (avg_ms * 1e-3) / 1e12,
+                        measured_peak_Tmad_s=31.5, frac=mads / (avg_ms * 1e-3) / 31.5e12)
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        valu_bound=valu,
                         kernel="bucket_accumulate30_kernel (G1 Pippenger bucket pass)", launches_per_step=len(bucket_g1) // args.steps,
                         avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg_bytes,
                         note="integer-VALU bound in practice (10 Fq products per 128 B); see DESIGN.md",

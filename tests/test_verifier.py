@@ -78,3 +78,29 @@ def test_gpu_proof_verifies(orc, cp):
     for pr in (proof, proof2):
         assert pm.verify_proof(cp, vk, _proof_from_flat(cp, pr.flat()), public)
     assert not pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), [(public[0] + 1) % cp.r])
+
+
+@pytest.mark.gpu
+def test_mimc322_prove_and_verify_gpu(orc):
+    """BASELINE.json configs[0]: the reference's integration test shape (tests/mimc.rs:145-229 -- MiMC with 322 rounds, 644
+    constraints, one public input; BLS12-377 there, BLS12-381 here as the config asks): setup, GPU proof with fresh r, s,
+    pairing verification on the image, rejection of a wrong image; the proof also equals the CPU oracle's bit for bit."""
+    import groth16_amd as g
+    from helpers import circuit_from_pymodel
+
+    cp = pm.BLS12_381
+    cs, z = pm.mimc_circuit(cp, 322, 5)
+    assert cs.num_constraints == 644 and cs.num_inputs == 2
+    ck = circuit_from_pymodel(cp, cs, z)
+    pk, ex = orc.setup(ck, 6)
+    mats = g.ConstraintMatrices(ck.num_inputs, ck.num_vars - ck.num_inputs, ck.num_constraints, *[(m.row_ptr, m.col, m.val) for m in ck.abc])
+    gpk = g.ProvingKey(cp.name, pk.alpha_g1, pk.beta_g1, pk.delta_g1, pk.beta_g2, pk.delta_g2, pk.a_query, pk.b_g1_query, pk.b_g2_query,
+                       pk.h_query, pk.l_query)
+    r, s = orc.rand_fr(cp.name, 8, 1)[0], orc.rand_fr(cp.name, 9, 1)[0]
+    with g.Groth16(cp.name, 0) as prover:
+        proof = prover.create_proof_with_reduction_and_matrices(gpk, r, s, mats, ck.num_inputs, ck.num_constraints, ck.z)
+    assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+    vk = _vk_from_oracle(cp, pk, ex)
+    image = z[1:2]
+    assert pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), image)
+    assert not pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), [(image[0] + 1) % cp.r])
