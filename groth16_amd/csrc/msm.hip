@@ -447,6 +447,10 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
     // >= ~4 segments per lane slot of the chip (256 CUs x 4 SIMDs x 2 waves x 64 lanes)
     uint32_t l = 128;
     while (l > 16 && (n * (uint64_t)plan->W) / l < 4ull * 131072ull) l >>= 1;
+    // ... but never much shorter than the mean bucket load: a bucket of ~mean entries then touches at most ~5 segments and
+    // stays below the heavy-bucket threshold (otherwise EVERY bucket would go through the cooperative combine)
+    const uint64_t mean = n / plan->B + 1;
+    while (l < 128 && (uint64_t)l * 4 < mean) l <<= 1;
     plan->Lmax = l;
     // histogram / scatter chunking: ~2048 workgroups in total, chunk a multiple of 1024 points
     uint64_t nchunks = 2048 / (uint64_t)plan->W;
