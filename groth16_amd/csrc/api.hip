@@ -285,12 +285,18 @@ struct Impl {
         };
         if (sharded) G16_TRY(enqueue_witness_map());
 
-        // ---- stream 1: assignment = full_assignment[1..] (prover.rs:80-85): ONE digit/sort pass for a, b_g1, b_g2 (and l)
-        G16_TRY(ctx->t_prep_z.start(s1));
-        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, ctx->arena, s1, &sort_z)));
-        G16_TRY(ctx->t_prep_z.stop(s1));
-        if (!sharded) {
-            G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));   // (re-recorded: now also covers the witness sort)
+        // ---- assignment = full_assignment[1..] (prover.rs:80-85): ONE digit/sort pass for a, b_g1, b_g2 (and l).
+        // Whole key: on stream 1, and the witness map is released behind it.  Sharded key: on stream 2, next to the
+        // witness map that occupies stream 1 (the sort's small kernels fit beside it).
+        hipStream_t s_sz = sharded ? s2 : s1;
+        if (sharded) G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
+        G16_TRY(ctx->t_prep_z.start(s_sz));
+        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, ctx->arena, s_sz, &sort_z)));
+        G16_TRY(ctx->t_prep_z.stop(s_sz));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_z, s_sz));   // (re-recorded: now also covers the witness sort)
+        if (sharded) {
+            G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_z, 0));
+        } else {
             G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
             G16_TRY(enqueue_witness_map());
         }

@@ -159,6 +159,24 @@ def test_proof_valid_crs_and_trapdoor(env, orc, g, k):
     assert (nozk.flat() == orc.prove(pk, ck, z4, z4)[0]).all()
 
 
+def test_proof_valid_crs_2_16_trapdoor_and_pairing(env, orc, g):
+    """a VALID proving key at 2^16 constraints (oracle setup, a few seconds): the GPU proof equals the closed form
+    computed from the trapdoor (scalar arithmetic and three fixed-base multiplications, no MSM) and passes the pairing verifier"""
+    from test_verifier import _proof_from_flat, _vk_from_oracle
+
+    curve, prover = env
+    cp = CP[curve]
+    ck = orc.syn_circuit(curve, 16, 21)
+    pk, ex = orc.setup(ck, 9)
+    r, s = orc.rand_fr(curve, 31, 1)[0], orc.rand_fr(curve, 32, 1)[0]
+    proof = prover.create_proof_with_reduction_and_matrices(pk_of(g, pk), r, s, mats_of(g, ck), ck.num_inputs, ck.num_constraints, ck.z)
+    assert (orc.trapdoor_proof(ck, ex, orc.witness_map(ck), r, s) == proof.flat()).all()
+    public = mont_to_ints(ck.z[1: ck.num_inputs], cp.r)
+    vk = _vk_from_oracle(cp, pk, ex)
+    assert pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), public)
+    assert not pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), [(public[0] + 1) % cp.r])
+
+
 def test_proof_golden_pymodel(env, orc, g):
     """MiMC and dense-row circuits generated by the big-int model (BASELINE config #1 shape)"""
     curve, prover = env
