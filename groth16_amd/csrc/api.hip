@@ -86,6 +86,10 @@ struct DevicePk {
     G2A* b_g2 = nullptr;
     uint64_t a_start = 0, a_count = 0, b_g1_start = 0, b_g1_count = 0, b_g2_start = 0, b_g2_count = 0;
     uint64_t h_start = 0, h_count = 0, l_start = 0, l_count = 0;
+    // window size of the precomputed window tables (msm.hip, merged windows): every query array then holds W rows of
+    // `count` points, row j = 2^(cj) * query.  0 = no tables (plain bases, per-window buckets).  a, b_g1, b_g2 and l share
+    // the witness sort and therefore one window size; h has its own.
+    int c_z = 0, c_h = 0;
 };
 
 struct g16_pk {
@@ -115,15 +119,41 @@ struct Impl {
     static constexpr int L = Fq::N / 2;  // 64-bit limbs per Fq
 
     // ---------------------------------------------------------------------------------------
-    template <class P>
-    static int upload_query(g16_ctx* ctx, const g16_query& q, bool dev_ptrs, P** out) {
+    // one query array of the key on the device, ready for the bucket kernel: with c == 0 the bases themselves (converted
+    // to the kernel's radix), else the W-row window table built from them; the caller's buffer is never modified
+    template <class F>
+    static int load_query(g16_ctx* ctx, const g16_query& q, bool dev_ptrs, int c, Affine<F>** out) {
+        typedef Affine<F> P;
         *out = nullptr;
         if (q.count == 0) return G16_OK;
         if (!q.points) return G16_ERR_BAD_ARG;
-        G16_HIP_TRY(hipMalloc((void**)out, q.count * sizeof(P)));
-        G16_HIP_TRY(hipMemcpyAsync(*out, q.points, q.count * sizeof(P), dev_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                   ctx->stream));
-        return G16_OK;
+        if (c == 0) {
+            if (hipMalloc((void**)out, q.count * sizeof(P)) != hipSuccess) return G16_ERR_OOM;
+            G16_HIP_TRY(hipMemcpyAsync(*out, q.points, q.count * sizeof(P), dev_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                       ctx->stream));
+            return convert_bases<F>(*out, q.count, ctx->stream);
+        }
+        uint32_t modw[Fr::N];
+        for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
+        const int W = msm_plan_windows(c, Fr::Params::BITS, modw, Fr::N);
+        if (W <= 0) return G16_ERR_INTERNAL;
+        if (hipMalloc((void**)out, q.count * sizeof(P) * (size_t)W) != hipSuccess) return G16_ERR_OOM;
+        const P* src = reinterpret_cast<const P*>(q.points);
+        P* staged = nullptr;
+        if (!dev_ptrs) {
+            if (hipMalloc((void**)&staged, q.count * sizeof(P)) != hipSuccess) return G16_ERR_OOM;
+            if (hipMemcpyAsync(staged, q.points, q.count * sizeof(P), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+                (void)hipFree(staged);
+                return G16_ERR_HIP;
+            }
+            src = staged;
+        }
+        int rc = build_window_tables<F>(src, q.count, c, W, *out, ctx->stream);
+        if (staged) {
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = rc ? rc : G16_ERR_HIP;
+            (void)hipFree(staged);
+        }
+        return rc;
     }
 
     static void pk_free(DevicePk<C>* p) {
@@ -148,17 +178,33 @@ struct Impl {
         p->b_g2_query0 = load_pod<G2A>(v->b_g2_query0);
         const bool dev = (v->flags & G16_PK_DEVICE_PTRS) != 0;
         int rc = G16_OK;
-        if ((rc = upload_query<G1A>(ctx, v->a, dev, &p->a)) || (rc = upload_query<G1A>(ctx, v->b_g1, dev, &p->b_g1)) ||
-            (rc = upload_query<G2A>(ctx, v->b_g2, dev, &p->b_g2)) || (rc = upload_query<G1A>(ctx, v->h, dev, &p->h)) ||
-            (rc = upload_query<G1A>(ctx, v->l, dev, &p->l))) {
-            pk_free(p);
-            return rc;
-        }
-        if ((rc = convert_bases<Fq>(p->a, v->a.count, ctx->stream)) || (rc = convert_bases<Fq>(p->b_g1, v->b_g1.count, ctx->stream)) ||
-            (rc = convert_bases<Fq>(p->h, v->h.count, ctx->stream)) || (rc = convert_bases<Fq>(p->l, v->l.count, ctx->stream)) ||
-            (rc = convert_bases<Fq2>(p->b_g2, v->b_g2.count, ctx->stream))) {
-            pk_free(p);
-            return rc;
+        // window tables (merged windows, msm.hip): a, b_g1, b_g2 and l share the witness sort, hence one window size
+        uint32_t modw[Fr::N];
+        for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
+        const uint64_t nz = std::max(std::max(v->a.count, v->b_g1.count), std::max(v->b_g2.count, v->l.count));
+        p->c_z = merged_window_bits(nz, Fr::Params::BITS, modw, Fr::N);
+        p->c_h = merged_window_bits(v->h.count, Fr::Params::BITS, modw, Fr::N);
+        if (v->h.count == 0) p->c_h = p->c_z;
+        if (nz == 0) p->c_z = p->c_h;
+        if (p->c_z == 0 || p->c_h == 0) p->c_z = p->c_h = 0;   // tables for all queries or for none
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const int cz = p->c_z, ch = p->c_h;
+            if ((rc = load_query<Fq>(ctx, v->a, dev, cz, &p->a)) || (rc = load_query<Fq>(ctx, v->b_g1, dev, cz, &p->b_g1)) ||
+                (rc = load_query<Fq2>(ctx, v->b_g2, dev, cz, &p->b_g2)) || (rc = load_query<Fq>(ctx, v->l, dev, cz, &p->l)) ||
+                (rc = load_query<Fq>(ctx, v->h, dev, ch, &p->h))) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipFree(p->a); (void)hipFree(p->b_g1); (void)hipFree(p->b_g2); (void)hipFree(p->h); (void)hipFree(p->l);
+                p->a = p->b_g1 = p->h = p->l = nullptr;
+                p->b_g2 = nullptr;
+                if (rc == G16_ERR_OOM && cz != 0) {   // the tables do not fit next to what already lives on this GPU: plain bases
+                    (void)hipGetLastError();
+                    p->c_z = p->c_h = 0;
+                    continue;
+                }
+                pk_free(p);
+                return rc;
+            }
+            break;
         }
         p->a_start = v->a.start; p->a_count = v->a.count;
         p->b_g1_start = v->b_g1.start; p->b_g1_count = v->b_g1.count;
@@ -278,7 +324,7 @@ struct Impl {
             G16_TRY(ctx->t_wm.stop(s_wm));
             // h's digit/sort pass follows on the same stream, so that the h bucket pass can start the moment stream 1 is free
             G16_TRY(ctx->t_prep_h.start(s_wm));
-            G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, ctx->arena, s_wm, &sort_h)));
+            G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, pk->c_h, ctx->arena, s_wm, &sort_h)));
             G16_TRY(ctx->t_prep_h.stop(s_wm));
             G16_HIP_TRY(hipEventRecord(ctx->ev_h, s_wm));
             return G16_OK;
@@ -291,7 +337,7 @@ struct Impl {
         hipStream_t s_sz = sharded ? s2 : s1;
         if (sharded) G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
         G16_TRY(ctx->t_prep_z.start(s_sz));
-        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, ctx->arena, s_sz, &sort_z)));
+        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, s_sz, &sort_z)));
         G16_TRY(ctx->t_prep_z.stop(s_sz));
         G16_HIP_TRY(hipEventRecord(ctx->ev_z, s_sz));   // (re-recorded: now also covers the witness sort)
         if (sharded) {
@@ -311,7 +357,7 @@ struct Impl {
             ctx->pinned_bytes = 5 * SLOT;
         }
         char* pin = static_cast<char*>(ctx->pinned);
-        if (sort_z.plan.W > 96) return G16_ERR_INTERNAL;
+        if (sort_z.plan.outputs() > 96 || sort_h.plan.outputs() > 96) return G16_ERR_INTERNAL;
         // bucket pass on stream 1; reduction + copy-out on stream 2
         auto run_msm = [&](int k, auto* bases, int64_t shift, uint64_t count, const ScalarSort& ss, auto* buf) -> int {
             typedef typename std::remove_pointer<decltype(buf)>::type Buf;
@@ -320,7 +366,7 @@ struct Impl {
             G16_HIP_TRY(hipEventRecord(ctx->ev_acc[k], s1));
             G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_acc[k], 0));
             G16_TRY((msm_reduce(*buf, ss, s2)));
-            G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf->window_sums, sizeof(*Buf().window_sums) * ss.plan.W, hipMemcpyDeviceToHost, s2));
+            G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf->window_sums, sizeof(*Buf().window_sums) * ss.plan.outputs(), hipMemcpyDeviceToHost, s2));
             G16_HIP_TRY(hipEventRecord(ctx->ev_done[k], s2));
             return G16_OK;
         };
@@ -334,7 +380,7 @@ struct Impl {
             const int64_t shift = (int64_t)pk->a_start - (int64_t)(nin - 1) - (int64_t)pk->l_start;
             G16_TRY(run_msm(1, pk->l, shift, pk->l_count, sort_z, &buf_l));
         } else {
-            G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, ctx->arena, s1, &sort_l)));
+            G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, pk->c_z, ctx->arena, s1, &sort_l)));
             G16_TRY(run_msm(1, pk->l, 0, pk->l_count, sort_l, &buf_l));
         }
         G16_TRY(run_msm(2, pk->a, 0, pk->a_count, sort_z, &buf_a));                                          // prover.rs:92
@@ -506,14 +552,29 @@ struct Impl {
             G16_HIP_TRY(hipMemcpyAsync(d_b, bases, n * sizeof(A), hipMemcpyHostToDevice, st));
             G16_HIP_TRY(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
         }
-        G16_TRY((convert_bases<F>(d_b, n, st)));
+        // ad-hoc bases: per-window buckets.  G16_MSM_API_PRECOMP=1 routes this entry point through the proving-key path
+        // instead (window tables built on the fly, merged windows) so that it can be tested on arbitrary inputs.
+        int merged_c = 0;
+        const char* e = getenv("G16_MSM_API_PRECOMP");
+        uint32_t modw[Fr::N];
+        for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
+        if (e && atoi(e) != 0 && n) merged_c = merged_window_bits(n, Fr::Params::BITS, modw, Fr::N);
+        if (merged_c) {
+            const int W = msm_plan_windows(merged_c, Fr::Params::BITS, modw, Fr::N);
+            A* d_t = nullptr;
+            G16_TRY(ctx->arena.alloc_n((size_t)n * W, &d_t));
+            G16_TRY((build_window_tables<F>(d_b, n, merged_c, W, d_t, st)));
+            d_b = d_t;
+        } else {
+            G16_TRY((convert_bases<F>(d_b, n, st)));
+        }
         ScalarSort ss;
-        G16_TRY((sort_scalars<C>(d_s, n, ctx->arena, st, &ss)));
+        G16_TRY((sort_scalars<C>(d_s, n, merged_c, ctx->arena, st, &ss)));
         MsmBuffers<F> buf;
         G16_TRY((msm_bucket_pass<F>(d_b, 0, n, ss, ctx->arena, st, &buf, &ctx->t_bucket[0])));
         G16_TRY((msm_reduce<F>(buf, ss, st)));
-        std::vector<X> hws(ss.plan.W);
-        G16_HIP_TRY(hipMemcpyAsync(hws.data(), buf.window_sums, sizeof(X) * ss.plan.W, hipMemcpyDeviceToHost, st));
+        std::vector<X> hws(ss.plan.outputs());
+        G16_HIP_TRY(hipMemcpyAsync(hws.data(), buf.window_sums, sizeof(X) * ss.plan.outputs(), hipMemcpyDeviceToHost, st));
         G16_HIP_TRY(hipStreamSynchronize(st));
         const A res = fold_windows<F>(hws.data(), ss.plan).to_affine();
         memcpy(out_affine, &res, sizeof(A));
@@ -602,8 +663,9 @@ struct Impl {
         memcpy(out, &r, sizeof(A));
         return G16_OK;
     }
-    // CPU model of kernels 1-7 of msm.hip: same plan, same digit/bucket/sign mapping, same chunked
-    // running-sum reduction and window fold.
+    // CPU model of kernels 1-7 of msm.hip: same plan, same digit/bucket/sign mapping, same chunked running-sum reduction
+    // and final fold.  c_override > 0: per-window plan with that window size; < 0: merged plan with window size -c_override
+    // (window tables 2^(cj) P_i built here by repeated doubling); 0: per-window plan from the cost model.
     template <class F>
     static int msm_model(const uint64_t* bases_, const uint64_t* scalars_, uint64_t n, int c_override, uint64_t* out) {
         typedef Affine<F> A;
@@ -616,11 +678,11 @@ struct Impl {
             snprintf(buf, sizeof(buf), "%d", c_override);
             setenv("G16_MSM_WINDOW", buf, 1);
         }
-        int rc = make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, &plan);
+        int rc = make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, c_override < 0 ? -c_override : 0, &plan);
         if (c_override > 0) unsetenv("G16_MSM_WINDOW");
         if (rc) return rc;
         const A* bases = reinterpret_cast<const A*>(bases_);
-        std::vector<X> buckets((size_t)plan.W * plan.B, X::identity());
+        std::vector<X> buckets((size_t)plan.buckets(), X::identity());
         for (uint64_t i = 0; i < n; ++i) {
             Fr s;
             memcpy(&s, scalars_ + 4 * i, sizeof(Fr));
@@ -636,16 +698,22 @@ struct Impl {
             A p;
             memcpy(&p, bases + i, sizeof(A));
             for (int w = 0; w < plan.W; ++w) {
+                if (plan.merged && w) {   // table row w: 2^(c w) P_i
+                    X d = X::from_affine(p);
+                    for (int k = 0; k < plan.c; ++k) d = d.dbl();
+                    p = d.to_affine();
+                }
                 uint32_t bucket, neg;
                 if (!digit_to_bucket(window_raw(sp, w, plan.c), plan.c, &bucket, &neg)) continue;
                 A q = p;
                 if (neg) q.y = q.y.neg();
-                buckets[(size_t)w * plan.B + bucket].add_affine(q);
+                // merged: `bucket` is the key over all 2^(c-1) buckets = group * B + bucket-in-group already
+                buckets[plan.merged ? (size_t)bucket : (size_t)w * plan.B + bucket].add_affine(q);
             }
         }
         const uint32_t G = plan.B >= 8 ? 8u : plan.B, cpw = plan.B / G;
-        std::vector<X> wsum(plan.W, X::identity());
-        for (int w = 0; w < plan.W; ++w) {
+        std::vector<X> wsum(plan.outputs(), X::identity());
+        for (int w = 0; w < plan.groups; ++w) {
             for (uint32_t ch = 0; ch < cpw; ++ch) {
                 const uint32_t b_lo = ch * G;
                 X run = X::identity(), tot = X::identity();
@@ -653,6 +721,7 @@ struct Impl {
                     run.add(buckets[(size_t)w * plan.B + b_lo + bb]);
                     tot.add(run);
                 }
+                if (plan.outputs() > plan.groups) wsum[plan.groups + w].add(run);
                 if (b_lo) {
                     uint32_t kk[1] = {b_lo};
                     int nb = 0;

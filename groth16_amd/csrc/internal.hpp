@@ -107,35 +107,50 @@ template <class C> int witness_map_device(const DeviceCircuit<C>* ck, const type
 
 // ---- MSM (msm.hip) ----------------------------------------------------------------------------
 struct MsmPlan {
-    int c = 0;          // window bits (<= 16)
+    int c = 0;          // window bits
     int W = 0;          // windows
-    uint32_t B = 0;     // buckets per window = 2^(c-1)
+    // Bucket groups.  Per-window mode (ad-hoc bases): one group per window, B = 2^(c-1) buckets each, c <= 16.
+    // Merged mode (proving-key queries with precomputed window tables T[j][i] = 2^(cj) P_i): every window's digits fall
+    // into ONE set of 2^(c-1) buckets (c <= 20), cut into `groups` = 2^(c-1) / B classes of B <= 2^15 buckets so that
+    // the LDS-resident counting sort and the reductions keep their shape.
+    int groups = 0;
+    bool merged = false;
+    uint32_t B = 0;     // buckets per group
     uint32_t Lmax = 0;  // segment length: sorted entries one bucket-pass lane walks (power of two)
     uint32_t chunk = 0; // points per histogram/scatter block
     uint32_t K[10];     // signed-digit bias  sum_w 2^(c-1) 2^(cw)
+    uint32_t buckets() const { return B * (uint32_t)groups; }
+    int outputs() const { return merged && groups > 1 ? 2 * groups : groups; }  // XYZZ sums leaving the device per MSM
 };
-int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, MsmPlan* plan);
+static constexpr int MSM_MERGED_MIN_C = 9, MSM_MERGED_MAX_C = 20;   // merged entries pack window j < 32 and point i < 2^26
+static constexpr uint64_t MSM_MERGED_MAX_N = (uint64_t)1 << 26;
+// merged_c = 0: per-window plan, window size from the cost model (or G16_MSM_WINDOW); else a merged plan with that c
+int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, int merged_c, MsmPlan* plan);
 int msm_window_override();  // env G16_MSM_WINDOW (0 = auto)
+// window size for the precomputed tables of a query with n bases (0 = no tables: disabled by G16_MSM_PRECOMP=0 or n too large)
+int merged_window_bits(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords);
+int msm_plan_windows(int c, int scalar_bits, const uint32_t* modulus_words, int mod_nwords);
 
 // digit extraction + bucket sort of one scalar array, shared by every MSM over those scalars
 struct ScalarSort {
     MsmPlan plan;
     uint64_t n = 0;
-    uint32_t* sorted = nullptr;    // [<= n*W] point index | sign<<31, grouped by (window, bucket)
-    uint32_t* offsets = nullptr;   // [W*B + 1] exclusive prefix of bucket sizes
-    uint32_t* task_off = nullptr;  // [W*B + 1] exclusive prefix of per-bucket partial-sum slots (one per segment a bucket touches)
+    uint32_t* sorted = nullptr;    // [<= n*W] point index | sign<<31 (merged: | window<<26), grouped by bucket
+    uint32_t* offsets = nullptr;   // [buckets + 1] exclusive prefix of bucket sizes
+    uint32_t* task_off = nullptr;  // [buckets + 1] exclusive prefix of per-bucket partial-sum slots (one per segment a bucket touches)
     uint32_t* heavy = nullptr;     // [0] = number of buckets with more than HEAVY_PARTS partials, then their ids
-    uint32_t max_tasks = 0;        // host-side upper bound on task_off[W*B] (partial slots)
+    uint32_t max_tasks = 0;        // host-side upper bound on task_off[buckets] (partial slots)
     uint32_t max_segments = 0;     // host-side upper bound on ceil(sorted entries / Lmax)
 };
-template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipStream_t st, ScalarSort* out);
+template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Arena& arena, hipStream_t st, ScalarSort* out);
 
 // Pippenger over one base array using a ScalarSort, in two stream-separable halves:
 //   msm_bucket_pass  the throughput-bound bucket accumulation.  Sorted index p addresses bases[p + shift] when
-//                    0 <= p + shift < base_count (other entries are skipped: lets l_query reuse the sort made for a/b)
+//                    0 <= p + shift < base_count (other entries are skipped: lets l_query reuse the sort made for a/b);
+//                    with a merged plan `d_bases` is the window table and entry (j, p) addresses [j * base_count + p + shift]
 //   msm_reduce       heavy-bucket combine, bucket reduction, window reduction (latency-bound, few waves): meant to
-//                    run on a second stream underneath the next MSM's bucket pass.  Leaves W window sums (standard
-//                    Montgomery form, XYZZ) in buf.window_sums.
+//                    run on a second stream underneath the next MSM's bucket pass.  Leaves plan.outputs() sums (standard
+//                    Montgomery form, XYZZ) in buf.window_sums: per group sum_b (b+1) S_b, then (merged) per group sum_b S_b.
 template <class F>
 struct MsmBuffers {
     void* partials = nullptr;    // AccRaw records (lazy limbs), one per (bucket, segment) pair
@@ -148,8 +163,11 @@ template <class F> int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss
 // MSM bases are kept on the device in the bucket kernel's own Montgomery radix (x*R' with R' = 2^(30 NL), canonical,
 // packed in the usual words): converted in place, once, after upload (F = Fq for G1, Fq2 for G2).
 template <class F> int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st);
-// host: sum_w 2^(c w) R_w
+// host: sum_w 2^(c w) R_w (per-window plan) or sum_q T_q + B sum_q q S_q (merged plan)
 template <class F> XYZZ<F> fold_windows(const XYZZ<F>* window_sums, const MsmPlan& plan);
+// window tables for a merged plan: table[j * n + i] = 2^(c j) * src[i] for j < W, affine, in the bucket kernel's radix
+// (what convert_bases leaves); src holds standard-form affine points and is not modified
+template <class F> int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine<F>* d_table, hipStream_t st);
 
 // ---- synthetic generators (synth.hip) -----------------------------------------------------------
 template <class C> int synth_bases_device(int g2, uint64_t seed, uint64_t first, uint64_t n, void* out_dev, hipStream_t st);

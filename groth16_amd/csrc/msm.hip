@@ -27,6 +27,14 @@
 // Steps 1-4 depend only on the scalars and are shared by every MSM over the same scalar
 // vector (a_query, b_g1_query, b_g2_query and l_query all use the witness: one sort, four
 // accumulations).
+//
+// MERGED WINDOWS (proving-key queries).  The bases of a proving key are fixed, so g16_pk_load precomputes the window
+// tables T[j][i] = 2^(cj) P_i (build_window_tables_kernel).  Window j's digit of scalar i then selects T[j][i] and ALL
+// windows share one set of 2^(c-1) buckets: sum_i s_i P_i = sum_b (b+1) sum_{(i,j): |d_ij|-1 = b} +-T[j][i].  The bucket
+// count no longer grows with the number of windows, so c rises from 16 to 20 and the bucket pass folds n*13 instead
+// of n*16 points (BLS12-381 and BN254 scalars); the 2^19 buckets are cut into 16 classes of 2^15 for the LDS histogram
+// (*_merged_kernel below), and the reductions treat a class like a window.  Costs 13x the key's memory (31 GB at 2^22
+// constraints on BLS12-381 -- HBM capacity is what this GPU has to spare) and a one-off table build at load time.
 // Roofline: step 5 reads ~N*W*(sizeof(Affine)+4) bytes (8.8 GB measured at 2^22, G1) but spends ~10 field
 // products (~3400 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
 // bytes/s it sustains is reported against the 8 TB/s roofline by bench.py regardless.
@@ -96,6 +104,96 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
         const uint32_t v = hist[b];
         if (v) atomicAdd(&out[b], v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1m/2m/4m. merged-window variants: every (point, window) digit is an entry of ONE bucket set of 2^(c-1) buckets, cut
+// into classes of B = 2^blog buckets.  Digit planes: a class byte (0xFF = zero digit) and a u16 (bucket in class | sign<<15)
+// per entry; workgroup (chunk, class q) walks all W planes of its point chunk and keeps the entries of class q.
+// Sorted entry = point | window << 26 | sign << 31.
+// ---------------------------------------------------------------------------------------------
+template <class Fr>
+__global__ __launch_bounds__(256) void digits_merged_kernel(const Fr* __restrict__ scalars, uint64_t n, uint64_t pstride, PlanDev plan,
+                                                            uint32_t blog, uint8_t* __restrict__ cls, uint16_t* __restrict__ lop) {
+    __shared__ uint32_t sw[MSM_SWORDS][256];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[Fr::N];
+    scalars[i].to_canonical(s);
+    uint64_t carry = 0;
+    G16_UNROLL for (int k = 0; k < 10; ++k) {
+        carry += (uint64_t)(k < Fr::N ? s[k] : 0u) + plan.K[k];
+        sw[k][threadIdx.x] = (uint32_t)carry;
+        carry >>= 32;
+    }
+    sw[10][threadIdx.x] = 0;
+    for (int w = 0; w < plan.W; ++w) {
+        const int bit = w * plan.c, word = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)sw[word][threadIdx.x] | ((uint64_t)sw[word + 1][threadIdx.x] << 32);
+        const uint32_t raw = (uint32_t)(two >> sh) & ((1u << plan.c) - 1u);
+        uint32_t key, neg;
+        const bool nz = digit_to_bucket(raw, plan.c, &key, &neg);
+        cls[(uint64_t)w * pstride + i] = nz ? (uint8_t)(key >> blog) : (uint8_t)0xFF;
+        lop[(uint64_t)w * pstride + i] = (uint16_t)((key & ((1u << blog) - 1u)) | (neg << 15));
+    }
+}
+
+static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_merged_kernel(const uint8_t* __restrict__ cls, const uint16_t* __restrict__ lop,
+                                                                           uint64_t n, uint64_t pstride, uint32_t chunk, int W, uint32_t B,
+                                                                           uint32_t* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t q = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) hist[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (int w = 0; w < W; ++w) {
+        const uint8_t* cp = cls + (uint64_t)w * pstride;
+        const uint16_t* lp = lop + (uint64_t)w * pstride;
+        for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS)
+            if (cp[p] == q) atomicAdd(&hist[lp[p] & 0x7fffu], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = counts + (uint64_t)q * B;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
+        const uint32_t v = hist[b];
+        if (v) atomicAdd(&out[b], v);
+    }
+}
+
+static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_merged_kernel(const uint8_t* __restrict__ cls, const uint16_t* __restrict__ lop,
+                                                                             uint64_t n, uint64_t pstride, uint32_t chunk, int W, uint32_t B,
+                                                                             const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                                             uint32_t* __restrict__ sorted) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t q = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) hist[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (int w = 0; w < W; ++w) {
+        const uint8_t* cp = cls + (uint64_t)w * pstride;
+        const uint16_t* lp = lop + (uint64_t)w * pstride;
+        for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS)
+            if (cp[p] == q) atomicAdd(&hist[lp[p] & 0x7fffu], 1u);
+    }
+    __syncthreads();
+    const uint64_t qb = (uint64_t)q * B;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
+        const uint32_t v = hist[b];
+        if (v) hist[b] = offsets[qb + b] + atomicAdd(&cursor[qb + b], v);
+    }
+    __syncthreads();
+    for (int w = 0; w < W; ++w) {
+        const uint8_t* cp = cls + (uint64_t)w * pstride;
+        const uint16_t* lp = lop + (uint64_t)w * pstride;
+        for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS)
+            if (cp[p] == q) {
+                const uint32_t d = lp[p];
+                const uint32_t pos = atomicAdd(&hist[d & 0x7fffu], 1u);
+                sorted[pos] = (uint32_t)p | ((uint32_t)w << 26) | ((d >> 15) << 31);
+            }
     }
 }
 
@@ -219,7 +317,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(con
 template <class F30>
 __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(
     const Affine<typename F30::Std>* __restrict__ bases, int64_t shift, uint64_t base_count, const uint32_t* __restrict__ sorted,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ slot_off, uint32_t M, uint32_t lseg_log,
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ slot_off, uint32_t M, uint32_t lseg_log, uint32_t merged,
     AccRaw<typename F30::Raw>* __restrict__ partials) {
     const uint32_t t = (blockIdx.x * ACC_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
     const uint32_t S = offsets[M];                                                          // sorted entries in total
@@ -240,9 +338,12 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
     bool ok_next = false;
     auto fetch = [&](uint32_t e) {
         v_next = sorted[e];
-        const int64_t idx = (int64_t)(v_next & 0x7fffffffu) + shift;
+        // per-window plan: entry = point | sign<<31 ; merged plan: point | window<<26 | sign<<31, base = table[window][point]
+        const uint32_t pt = merged ? (v_next & 0x3ffffffu) : (v_next & 0x7fffffffu);
+        const uint64_t row = merged ? (uint64_t)((v_next >> 26) & 31u) * base_count : 0;
+        const int64_t idx = (int64_t)pt + shift;
         ok_next = idx >= 0 && (uint64_t)idx < base_count;
-        if (ok_next) ok_next = F30::load_point(bases, idx, px_next, py_next);
+        if (ok_next) ok_next = F30::load_point(bases, (int64_t)(row + (uint64_t)idx), px_next, py_next);
     };
     fetch(start);
     for (uint32_t e = start; e < end; ++e) {
@@ -336,7 +437,7 @@ __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(AccRaw<F30>
 template <class F30>
 __global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw<F30>* __restrict__ partials,
                                                                     const uint32_t* __restrict__ slot_off, uint32_t B, int W, uint32_t G,
-                                                                    AccRaw<F30>* __restrict__ chunk_out) {
+                                                                    AccRaw<F30>* __restrict__ chunk_out, AccRaw<F30>* __restrict__ chunk_sum) {
     const uint32_t cpw = B / G;
     const uint32_t t = blockIdx.x * RED_THREADS + threadIdx.x;
     if (t >= cpw * (uint32_t)W) return;
@@ -351,6 +452,7 @@ __global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw
         tot.add(run);
     }
     // sum_b (b+1) S_b over the chunk = tot + b_lo * run
+    if (chunk_sum) run.store_raw(&chunk_sum[t]);   // merged plan: the group's plain sum is needed too
     if (b_lo) tot.add(run.mul_small(b_lo));
     tot.store_raw(&chunk_out[t]);
 }
@@ -418,42 +520,86 @@ static int plan_windows(int c, int scalar_bits, const uint32_t* modulus_words, i
     }
 }
 
-int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, MsmPlan* plan) {
-    int c = msm_window_override();
+int msm_plan_windows(int c, int scalar_bits, const uint32_t* modulus_words, int mod_nwords) {
+    return plan_windows(c, scalar_bits, modulus_words, mod_nwords, nullptr);
+}
+
+// seconds, MI355X measurements of round 1: the bucket pass folds entries at ~4.5 G mixed adds/s; the bucket reduction is
+// buckets/G lanes of (2G + ~24) dependent full additions, latency-bound (~12 us each) until the lanes exceed two waves
+// per SIMD; per-group bookkeeping ~4 us
+static double plan_cost(uint64_t n, int W, double buckets, int groups) {
+    const double acc = (double)n * W / 4.5e9;
+    const double lanes = buckets / REDUCE_G;
+    const double red = (2.0 * REDUCE_G + 24.0) * 12e-6 * (lanes > 131072.0 ? lanes / 131072.0 : 1.0);
+    return acc + red + 4e-6 * groups;
+}
+
+int merged_window_bits(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords) {
+    const char* e = getenv("G16_MSM_PRECOMP");
+    if (e && atoi(e) == 0) return 0;
+    if (n == 0 || n > MSM_MERGED_MAX_N) return 0;
+    const char* f = getenv("G16_MSM_PRECOMP_WINDOW");
+    int c = f ? atoi(f) : 0;
     if (c <= 0) {
-        // cost model (seconds, MI355X measurements of round 1): the bucket pass folds n*W points at ~4.5 G mixed adds/s;
-        // the bucket reduction is W*B/G lanes of (2G + ~24) dependent full additions, latency-bound (~12 us each) until
-        // the lanes exceed two waves per SIMD.
         double best = 1e300;
-        for (int cc = 4; cc <= 16; ++cc) {
+        for (int cc = MSM_MERGED_MIN_C; cc <= MSM_MERGED_MAX_C; ++cc) {
             const int W = plan_windows(cc, scalar_bits, modulus_words, mod_nwords, nullptr);
-            if (W < 0) continue;
-            const double B = (double)(1u << (cc - 1));
-            const double acc = (double)n * W / 4.5e9;
-            const double lanes = W * B / REDUCE_G;
-            const double red = (2.0 * REDUCE_G + 24.0) * 12e-6 * (lanes > 131072.0 ? lanes / 131072.0 : 1.0);
-            const double launch = 4e-6 * W;  // per-window bookkeeping
-            if (acc + red + launch < best) { best = acc + red + launch; c = cc; }
+            if (W < 0 || W > 32) continue;
+            const double buckets = (double)(1u << (cc - 1));
+            const int groups = cc > 16 ? 1 << (cc - 16) : 1;
+            // the class filter of the merged counting sort re-reads the digit planes once per class
+            const double t = plan_cost(n, W, buckets, groups) + (double)n * W * groups * 3.0 / 1.5e12;
+            if (t < best) { best = t; c = cc; }
         }
     }
-    if (c < 3) c = 3;
-    if (c > 16) c = 16;
+    if (c < MSM_MERGED_MIN_C) c = MSM_MERGED_MIN_C;
+    if (c > MSM_MERGED_MAX_C) c = MSM_MERGED_MAX_C;
+    const int W = plan_windows(c, scalar_bits, modulus_words, mod_nwords, nullptr);
+    return (W < 0 || W > 32) ? 0 : c;
+}
+
+int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, int merged_c, MsmPlan* plan) {
+    int c = merged_c;
+    if (c <= 0) {
+        c = msm_window_override();
+        if (c <= 0) {
+            double best = 1e300;
+            for (int cc = 4; cc <= 16; ++cc) {
+                const int W = plan_windows(cc, scalar_bits, modulus_words, mod_nwords, nullptr);
+                if (W < 0) continue;
+                const double t = plan_cost(n, W, (double)W * (1u << (cc - 1)), W);
+                if (t < best) { best = t; c = cc; }
+            }
+        }
+        if (c < 3) c = 3;
+        if (c > 16) c = 16;
+    } else if (c < MSM_MERGED_MIN_C || c > MSM_MERGED_MAX_C || n > MSM_MERGED_MAX_N) {
+        return G16_ERR_INTERNAL;
+    }
     const int W = plan_windows(c, scalar_bits, modulus_words, mod_nwords, plan->K);
-    if (W < 0) return G16_ERR_INTERNAL;
+    if (W < 0 || (merged_c > 0 && W > 32)) return G16_ERR_INTERNAL;
     plan->c = c;
     plan->W = W;
-    plan->B = 1u << (c - 1);
+    plan->merged = merged_c > 0;
+    if (plan->merged) {
+        plan->B = 1u << (c > 16 ? 15 : c - 1);
+        plan->groups = c > 16 ? 1 << (c - 16) : 1;
+    } else {
+        plan->B = 1u << (c - 1);
+        plan->groups = W;
+    }
+    const uint64_t entries = n * (uint64_t)W;
     // segment length of the bucket pass: 128 entries per lane, shorter for small inputs so that the pass still has
     // >= ~4 segments per lane slot of the chip (256 CUs x 4 SIMDs x 2 waves x 64 lanes)
     uint32_t l = 128;
-    while (l > 16 && (n * (uint64_t)plan->W) / l < 4ull * 131072ull) l >>= 1;
+    while (l > 16 && entries / l < 4ull * 131072ull) l >>= 1;
     // ... but never much shorter than the mean bucket load: a bucket of ~mean entries then touches at most ~5 segments and
     // stays below the heavy-bucket threshold (otherwise EVERY bucket would go through the cooperative combine)
-    const uint64_t mean = n / plan->B + 1;
+    const uint64_t mean = entries / plan->buckets() + 1;
     while (l < 128 && (uint64_t)l * 4 < mean) l <<= 1;
     plan->Lmax = l;
     // histogram / scatter chunking: ~2048 workgroups in total, chunk a multiple of 1024 points
-    uint64_t nchunks = 2048 / (uint64_t)plan->W;
+    uint64_t nchunks = 2048 / (uint64_t)plan->groups;
     if (nchunks < 1) nchunks = 1;
     uint64_t chunk = (n + nchunks - 1) / nchunks;
     chunk = (chunk + 1023) / 1024 * 1024;
@@ -467,21 +613,24 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
 static int ilog2(uint32_t v) { int l = 0; while ((1u << l) < v) ++l; return l; }
 
 template <class C>
-int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipStream_t st, ScalarSort* out) {
+int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Arena& arena, hipStream_t st, ScalarSort* out) {
     typedef typename C::Fr Fr;
     if (n >= ((uint64_t)1 << 31)) return G16_ERR_BAD_LENGTH;
     uint32_t modw[Fr::N];
     for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
     MsmPlan plan;
-    G16_TRY(make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, &plan));
+    G16_TRY(make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, merged_c, &plan));
     out->plan = plan;
     out->n = n;
-    const uint32_t M = plan.B * (uint32_t)plan.W;
+    const uint32_t M = plan.buckets();
     const uint64_t nw = n * (uint64_t)plan.W;
     if (nw >= ((uint64_t)1 << 32)) return G16_ERR_BAD_LENGTH;
+    const uint64_t pstride = (n + 15) & ~(uint64_t)15;   // merged digit planes: one row per window
     uint16_t* planes = nullptr;
+    uint8_t* cls = nullptr;
     uint32_t *counts = nullptr, *cursor = nullptr, *nparts = nullptr, *block_sums = nullptr;
-    G16_TRY(arena.alloc_n(nw ? nw : 1, &planes));
+    G16_TRY(arena.alloc_n(plan.merged ? pstride * plan.W + 16 : (nw ? nw : 1), &planes));
+    if (plan.merged) G16_TRY(arena.alloc_n(pstride * plan.W + 16, &cls));
     G16_TRY(arena.alloc_n((size_t)3 * M + 1, &counts));  // counts | scatter cursors | heavy count + list
     cursor = counts + M;
     out->heavy = counts + 2 * (size_t)M;
@@ -502,14 +651,27 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
                                         128 * 1024));
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         128 * 1024));
+        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_count_merged_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_scatter_merged_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
     const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
+    const uint32_t blog = (uint32_t)ilog2(plan.B);
     if (n) {
-        hipLaunchKernelGGL((digits_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pd, planes);
-        G16_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bucket_count_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
-                           counts);
+        if (plan.merged) {
+            hipLaunchKernelGGL((digits_merged_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pstride, pd, blog,
+                               cls, planes);
+            G16_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bucket_count_merged_kernel, dim3(nchunks, plan.groups), dim3(SORT_THREADS), lds, st, cls, planes, n, pstride,
+                               plan.chunk, plan.W, plan.B, counts);
+        } else {
+            hipLaunchKernelGGL((digits_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pd, planes);
+            G16_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bucket_count_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
+                               counts);
+        }
         G16_LAUNCH_CHECK();
     }
     const uint32_t nblocks = (M + SCAN_TILE - 1) / SCAN_TILE, lseg_log = (uint32_t)ilog2(plan.Lmax);
@@ -528,8 +690,12 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, Arena& arena, hipS
     G16_LAUNCH_CHECK();
     G16_TRY(prefix_scan(nparts, out->task_off));
     if (n) {
-        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
-                           out->offsets, cursor, out->sorted);
+        if (plan.merged)
+            hipLaunchKernelGGL(bucket_scatter_merged_kernel, dim3(nchunks, plan.groups), dim3(SORT_THREADS), lds, st, cls, planes, n, pstride,
+                               plan.chunk, plan.W, plan.B, out->offsets, cursor, out->sorted);
+        else
+            hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
+                               out->offsets, cursor, out->sorted);
         G16_LAUNCH_CHECK();
     }
     return G16_OK;
@@ -541,20 +707,21 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
     typedef typename Lazy30<F>::acc_type F30;
     typedef AccRaw<typename Lazy30<F>::type> Raw;
     const MsmPlan& plan = ss.plan;
-    const uint32_t M = plan.B * (uint32_t)plan.W;
+    const uint32_t M = plan.buckets();
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
     Raw *partials = nullptr, *chunk_out = nullptr;
     G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
-    G16_TRY(arena.alloc_n((size_t)cpw * plan.W, &chunk_out));
-    G16_TRY(arena.alloc_n((size_t)plan.W, &out->window_sums));
+    G16_TRY(arena.alloc_n((size_t)cpw * plan.outputs(), &chunk_out));   // (b+1)-weighted chunk sums, then (merged) plain chunk sums
+    G16_TRY(arena.alloc_n((size_t)plan.outputs(), &out->window_sums));
     out->partials = partials;
     out->chunk_out = chunk_out;
     if (bucket_timer) G16_TRY(bucket_timer->start(st));
     if (ss.max_segments) {
         const uint64_t lanes = (uint64_t)ss.max_segments * F30::LANES_PER_TASK;
         hipLaunchKernelGGL((bucket_accumulate30_kernel<F30>), dim3((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
-                           st, d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax), partials);
+                           st, d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax),
+                           plan.merged ? 1u : 0u, partials);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));
@@ -581,10 +748,13 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     Raw* chunk_out = static_cast<Raw*>(buf.chunk_out);
     hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, partials, ss.task_off, ss.heavy);
     G16_LAUNCH_CHECK();
-    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.W + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st, partials,
-                       ss.task_off, plan.B, plan.W, G, chunk_out);
+    const bool sums = plan.outputs() > plan.groups;
+    Raw* chunk_sum = sums ? chunk_out + (size_t)cpw * plan.groups : nullptr;
+    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st,
+                       partials, ss.task_off, plan.B, plan.groups, G, chunk_out, chunk_sum);
     G16_LAUNCH_CHECK();
-    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.W), dim3(WIN_THREADS), lds_win, st, chunk_out, cpw, buf.window_sums);
+    // chunk_out and chunk_sum are contiguous: one launch reduces outputs() rows of cpw chunks each
+    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.outputs()), dim3(WIN_THREADS), lds_win, st, chunk_out, cpw, buf.window_sums);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
@@ -600,6 +770,17 @@ int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st) {
 template <class F>
 XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
     XYZZ<F> total = XYZZ<F>::identity();
+    if (plan.merged) {
+        // bucket value of (group q, bucket b) is q*B + b + 1:  sum = sum_q T_q + B * sum_q q S_q
+        const int Q = plan.groups;
+        if (Q > 1) {
+            XYZZ<F> run = XYZZ<F>::identity();
+            for (int q = Q - 1; q >= 1; --q) { run.add(ws[Q + q]); total.add(run); }
+            for (uint32_t b = plan.B; b > 1; b >>= 1) total = total.dbl();
+        }
+        for (int q = 0; q < Q; ++q) total.add(ws[q]);
+        return total;
+    }
     for (int w = plan.W - 1; w >= 0; --w) {
         for (int k = 0; k < plan.c; ++k) total = total.dbl();
         total.add(ws[w]);
@@ -607,10 +788,56 @@ XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
     return total;
 }
 
+// table[j * n + i] = 2^(c j) P_i.  One lane per point: W-1 runs of c doublings in XYZZ, ONE field inversion for all of
+// them (Montgomery's trick over the ZZ*ZZZ products), output in the bucket kernel's radix.  Runs once per key.
+static constexpr int TABLE_MAX_W = 32;
+template <class F>
+__global__ __launch_bounds__(64) void build_window_tables_kernel(const Affine<F>* __restrict__ src, uint64_t n, int c, int W,
+                                                                  Affine<F>* __restrict__ table) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine<F> p = src[i];
+    Affine<F> o;
+    o.x = to_r30(p.x); o.y = to_r30(p.y);
+    table[i] = o;
+    XYZZ<F> pt[TABLE_MAX_W];
+    F pre[TABLE_MAX_W];
+    XYZZ<F> acc = XYZZ<F>::from_affine(p);
+    F run = F::one();
+    for (int j = 1; j < W; ++j) {
+        for (int k = 0; k < c; ++k) acc = acc.dbl();
+        pt[j] = acc;
+        pre[j] = run;                                  // product of the t's before j
+        if (!acc.is_identity()) run = run * (acc.zz * acc.zzz);
+    }
+    F inv = run.inverse();                             // run != 0: a product of non-zero ZZ*ZZZ (or one)
+    for (int j = W - 1; j >= 1; --j) {
+        Affine<F> a = Affine<F>::identity();
+        if (!pt[j].is_identity()) {
+            const F it = inv * pre[j];                 // 1 / (ZZ ZZZ)
+            inv = inv * (pt[j].zz * pt[j].zzz);
+            a.x = to_r30(pt[j].x * (it * pt[j].zzz));  // X / ZZ
+            a.y = to_r30(pt[j].y * (it * pt[j].zz));   // Y / ZZZ
+        }
+        table[(uint64_t)j * n + i] = a;
+    }
+}
+
+template <class F>
+int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine<F>* d_table, hipStream_t st) {
+    if (n == 0) return G16_OK;
+    if (W > TABLE_MAX_W) return G16_ERR_INTERNAL;
+    hipLaunchKernelGGL((build_window_tables_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_src, n, c, W, d_table);
+    G16_LAUNCH_CHECK();
+    return G16_OK;
+}
+
 #define G16_INSTANTIATE_MSM(C)                                                                                               \
     template int convert_bases<typename C::Fq>(Affine<typename C::Fq>*, uint64_t, hipStream_t);                             \
     template int convert_bases<typename C::Fq2>(Affine<typename C::Fq2>*, uint64_t, hipStream_t);                           \
-    template int sort_scalars<C>(const typename C::Fr*, uint64_t, Arena&, hipStream_t, ScalarSort*);                        \
+    template int sort_scalars<C>(const typename C::Fr*, uint64_t, int, Arena&, hipStream_t, ScalarSort*);                   \
+    template int build_window_tables<typename C::Fq>(const Affine<typename C::Fq>*, uint64_t, int, int, Affine<typename C::Fq>*, hipStream_t);    \
+    template int build_window_tables<typename C::Fq2>(const Affine<typename C::Fq2>*, uint64_t, int, int, Affine<typename C::Fq2>*, hipStream_t); \
     template int msm_bucket_pass<typename C::Fq>(const Affine<typename C::Fq>*, int64_t, uint64_t, const ScalarSort&, Arena&, \
                                                  hipStream_t, MsmBuffers<typename C::Fq>*, EventTimer*);                      \
     template int msm_bucket_pass<typename C::Fq2>(const Affine<typename C::Fq2>*, int64_t, uint64_t, const ScalarSort&,     \

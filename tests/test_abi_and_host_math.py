@@ -91,14 +91,15 @@ def test_host_group_ops(lb, orc, cp):
 
 
 @pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("c_win", [0, 3, 5, 9, 13, 16])
+@pytest.mark.parametrize("c_win", [0, 3, 5, 9, 13, 16, -9, -12, -16, -17, -20])
 def test_host_msm_model(lb, orc, cp, c_win):
     """the signed-digit / bucket / chunked-reduction / fold scheme the kernels implement, run on the
-    CPU with the kernels' own helper code, against the oracle's ark-ec style Pippenger"""
+    CPU with the kernels' own helper code, against the oracle's ark-ec style Pippenger.  Negative c_win: the merged-window
+    scheme of the proving-key path (window tables 2^(cj) P, one bucket set cut into classes of 2^15, fold over classes)."""
     cid = CURVE_ID[cp.name]
-    n = 70 if c_win >= 13 else 300
+    n = 70 if abs(c_win) >= 13 else 300
     for g2 in (0, 1):
-        if g2 and c_win in (9, 16):
+        if g2 and c_win in (9, 16, -12, -16, -20):
             continue
         bases = orc.synth_bases(cp.name, bool(g2), 5, n)
         sc = orc.rand_fr(cp.name, 77 + c_win, n)

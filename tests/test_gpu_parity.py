@@ -79,9 +79,22 @@ def test_witness_map_padded_domain_and_dense_rows(env, orc, g):
         assert mont_to_ints(h, cp.r) == pm.witness_map_from_matrices(cp, cs, z)
 
 
+@pytest.fixture(params=["per_window", "merged", "merged_c17", "merged_c20"])
+def msm_path(request, monkeypatch):
+    """which bucket scheme g16_msm_* runs: per-window buckets (ad-hoc bases, the default of that entry point) or the
+    proving-key scheme -- window tables + merged windows -- with the window size from the cost model or forced so that the
+    bucket set is cut into 2 / 16 classes (the shape a 2^22 key uses) even at test sizes.  The library reads the
+    variables at call time."""
+    if request.param != "per_window":
+        monkeypatch.setenv("G16_MSM_API_PRECOMP", "1")
+    if request.param.startswith("merged_c"):
+        monkeypatch.setenv("G16_MSM_PRECOMP_WINDOW", request.param[len("merged_c"):])
+    return request.param
+
+
 @pytest.mark.parametrize("g2", [False, True])
 @pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 257, 4096, 20000])
-def test_msm_matches_oracle(env, orc, g2, n):
+def test_msm_matches_oracle(env, orc, g2, n, msm_path):
     curve, prover = env
     bases = orc.synth_bases(curve, g2, 3, max(n, 1))[:n]
     sc = orc.rand_fr(curve, 7 + n, max(n, 1))[:n]
@@ -91,7 +104,7 @@ def test_msm_matches_oracle(env, orc, g2, n):
 
 
 @pytest.mark.parametrize("g2", [False, True])
-def test_msm_adversarial_inputs(env, orc, g2):
+def test_msm_adversarial_inputs(env, orc, g2, msm_path):
     """zero scalars, r-1, all-equal scalars (benches/bench.rs:52-54 shape), identity bases, repeated
     bases, P and -P in the same bucket, all-zero, all-one"""
     curve, prover = env
@@ -120,8 +133,11 @@ def test_msm_adversarial_inputs(env, orc, g2):
         assert (prover.msm(bases, scal, g2) == orc.msm(curve, g2, bases, scal)).all()
 
 
-def test_msm_linearity_large(env, orc):
+@pytest.mark.parametrize("path", ["per_window", "merged"])
+def test_msm_linearity_large(env, orc, path, monkeypatch):
     """size-independent property at 2^20 points: msm(b, s1) + msm(b, s2) == msm(b, s1 + s2)"""
+    if path == "merged":
+        monkeypatch.setenv("G16_MSM_API_PRECOMP", "1")
     curve, prover = env
     cp = CP[curve]
     n = 1 << 20
@@ -175,6 +191,27 @@ def test_proof_valid_crs_2_16_trapdoor_and_pairing(env, orc, g):
     vk = _vk_from_oracle(cp, pk, ex)
     assert pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), public)
     assert not pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), [(public[0] + 1) % cp.r])
+
+
+@pytest.mark.parametrize("scheme", [{"G16_MSM_PRECOMP": "0"}, {"G16_MSM_PRECOMP_WINDOW": "16"}, {"G16_MSM_PRECOMP_WINDOW": "17"},
+                                    {"G16_MSM_PRECOMP_WINDOW": "20"}], ids=["plain_bases", "tables_c16", "tables_c17", "tables_c20"])
+def test_proof_bucket_schemes(env, orc, g, scheme, monkeypatch):
+    """g16_pk_load decides how the key is held (plain bases + per-window buckets, or window tables + merged windows at
+    the window size of the cost model); every choice must give the oracle's proof, including the 16-class shape of a
+    2^22 key and a sharded key whose l range needs its own sort"""
+    curve, prover = env
+    for k_, v in scheme.items():
+        monkeypatch.setenv(k_, v)
+    ck = orc.syn_circuit(curve, 9, 5)
+    pk, _ = orc.setup(ck, 6)
+    gm = mats_of(g, ck)
+    r, s = orc.rand_fr(curve, 41, 1)[0], orc.rand_fr(curve, 42, 1)[0]
+    want, _ = orc.prove(pk, ck, r, s)
+    proof = prover.create_proof_with_reduction_and_matrices(pk_of(g, pk), r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
+    assert (proof.flat() == want).all()
+    gp = pk_of(g, pk)
+    parts = [prover.prove_partial(gp, gm, ck.z, (i, 3)) for i in range(3)]
+    assert (prover.prove_finalize(gp, ck.num_inputs, parts, r, s, (0, 3)).flat() == want).all()
 
 
 def test_proof_golden_pymodel(env, orc, g):
