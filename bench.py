@@ -254,14 +254,14 @@ def main():
         proof = prove_step(p, dist, device)
     barrier()
     t0 = time.perf_counter()
-    bucket_g1, bucket_g2, phase_acc = [], [], {}
+    bucket_g1, bucket_g2, phase_acc, last_tm = [], [], {}, {}
     for _ in range(args.steps):
         proof = prove_step(p, dist, device)
-        tm = p.timings()  # event timers already resolved; no extra device work
+        tm = last_tm = p.timings()  # event timers already resolved; no extra device work
         bucket_g1 += [x for x in tm["bucket_ms"][:4] if x > 0]
         bucket_g2.append(tm["bucket_ms"][4])
         for k_, v in tm.items():
-            if k_ != "bucket_ms":
+            if k_ not in ("bucket_ms", "window_bits", "windows"):
                 phase_acc[k_] = phase_acc.get(k_, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
@@ -298,12 +298,13 @@ def main():
         # the bound that actually applies: v_mad_u64_u32 issue.  One G1 mixed addition = 8 products (338
         # multiply-adds each) + 2 squarings (260); the chip issues at most one v_mad_u64_u32 per ~5 cycles per SIMD
         # (measured, profiles/r01_ubench.txt): 1024 SIMDs x 64 lanes x 2.4 GHz / 5 = 31.5 T multiply-adds/s.
-        n_windows = 16 if args.log2 >= 16 else None
+        n_windows = int(last_tm.get("windows", 0))
         valu = None
         if n_windows:
             mads = float(n_pts) * n_windows * (8 * 338 + 2 * 260 if args.curve == "bls12_381" else 8 * 162 + 2 * 126)
             valu = dict(kind="v_mad_u64_u32 issue (integer VALU)", mads_per_launch=mads, achieved_Tmad_s=mads / (avg_ms * 1e-3) / 1e12,
-                        measured_peak_Tmad_s=31.5, frac=mads / (avg_ms * 1e-3) / 31.5e12)
+                        measured_peak_Tmad_s=31.5, frac=mads / (avg_ms * 1e-3) / 31.5e12, window_bits=int(last_tm.get("window_bits", 0)),
+                        windows=n_windows, points_folded_per_launch=n_pts * n_windows)
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         valu_bound=valu,
                         kernel="bucket_accumulate30_kernel (G1 Pippenger bucket pass)", launches_per_step=len(bucket_g1) // args.steps,

@@ -60,11 +60,12 @@ struct g16_ctx {
     int curve;
     int device;
     hipStream_t stream;   // bucket passes, digit/sort
-    hipStream_t stream2;  // witness map and the latency-bound reductions, underneath the bucket passes
+    hipStream_t stream2;  // witness digit/sort pass, then the latency-bound reductions underneath the bucket passes
+    hipStream_t stream3;  // h's digit/sort pass, underneath the first bucket pass
     Arena arena;
     g16_timings tm;
     EventTimer t_wm, t_prep_h, t_prep_z, t_bucket[5];
-    hipEvent_t ev_z = nullptr, ev_h = nullptr, ev_acc[5] = {}, ev_done[5] = {}, ev_msm_start[5] = {};
+    hipEvent_t ev_z = nullptr, ev_h = nullptr, ev_wm = nullptr, ev_acc[5] = {}, ev_done[5] = {}, ev_msm_start[5] = {};
     void* pinned = nullptr;  // window sums land here (hipHostMalloc)
     size_t pinned_bytes = 0;
 };
@@ -291,7 +292,7 @@ struct Impl {
                              int skip_b_g1, g16_partial* out) {
         const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
         const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
-        hipStream_t s1 = ctx->stream, s2 = ctx->stream2;
+        hipStream_t s1 = ctx->stream, s2 = ctx->stream2, s3 = ctx->stream3;
         if (n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
         const uint64_t n = ck->dom->n, nin = ck->num_inputs;
         const uint64_t m = n_assign - 1, w = n_assign - nin;
@@ -308,44 +309,31 @@ struct Impl {
         G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
         G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));
 
-        // ---- witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it.
-        // Whole key on this GPU: it runs on stream 2 underneath the (much longer) bucket passes, and is released only once
-        // the witness digit/sort pass has finished, so that the first bucket pass starts as early as possible.
-        // Sharded key (this rank holds < 1/3 of the bases, but the witness map is replicated at full size): the bucket
-        // passes are too short to hide it and their long-lived waves would starve it, so it goes first, alone, on stream 1.
+        // ---- witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it.  It goes FIRST,
+        // alone, on stream 1 (~6 ms at 2^22): underneath the bucket passes their long-lived waves starve it (60+ ms
+        // measured) and everything queued behind it piles up at the end of the proof.
         Fr* d_h = nullptr;
         G16_TRY(ctx->arena.alloc_n(n, &d_h));
-        const bool sharded = pk->a_count * 3 < m;
-        hipStream_t s_wm = sharded ? s1 : s2;
         ScalarSort sort_h, sort_z, sort_l;
-        auto enqueue_witness_map = [&]() -> int {
-            G16_TRY(ctx->t_wm.start(s_wm));
-            G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s_wm)));
-            G16_TRY(ctx->t_wm.stop(s_wm));
-            // h's digit/sort pass follows on the same stream, so that the h bucket pass can start the moment stream 1 is free
-            G16_TRY(ctx->t_prep_h.start(s_wm));
-            G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, pk->c_h, ctx->arena, s_wm, &sort_h)));
-            G16_TRY(ctx->t_prep_h.stop(s_wm));
-            G16_HIP_TRY(hipEventRecord(ctx->ev_h, s_wm));
-            return G16_OK;
-        };
-        if (sharded) G16_TRY(enqueue_witness_map());
+        G16_TRY(ctx->t_wm.start(s1));
+        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1)));
+        G16_TRY(ctx->t_wm.stop(s1));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_wm, s1));
 
-        // ---- assignment = full_assignment[1..] (prover.rs:80-85): ONE digit/sort pass for a, b_g1, b_g2 (and l).
-        // Whole key: on stream 1, and the witness map is released behind it.  Sharded key: on stream 2, next to the
-        // witness map that occupies stream 1 (the sort's small kernels fit beside it).
-        hipStream_t s_sz = sharded ? s2 : s1;
-        if (sharded) G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
-        G16_TRY(ctx->t_prep_z.start(s_sz));
-        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, s_sz, &sort_z)));
-        G16_TRY(ctx->t_prep_z.stop(s_sz));
-        G16_HIP_TRY(hipEventRecord(ctx->ev_z, s_sz));   // (re-recorded: now also covers the witness sort)
-        if (sharded) {
-            G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_z, 0));
-        } else {
-            G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
-            G16_TRY(enqueue_witness_map());
-        }
+        // ---- stream 2, beside the witness map: assignment = full_assignment[1..] (prover.rs:80-85), ONE digit/sort
+        // pass for a, b_g1, b_g2 (and l)
+        G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
+        G16_TRY(ctx->t_prep_z.start(s2));
+        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, s2, &sort_z)));
+        G16_TRY(ctx->t_prep_z.stop(s2));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_z, s2));   // (re-recorded: now also covers the witness sort)
+        G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_z, 0));
+        // ---- stream 3: h's digit/sort pass, underneath the first bucket pass (stream 2 stays free for the reductions)
+        G16_HIP_TRY(hipStreamWaitEvent(s3, ctx->ev_wm, 0));
+        G16_TRY(ctx->t_prep_h.start(s3));
+        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, pk->c_h, ctx->arena, s3, &sort_h)));
+        G16_TRY(ctx->t_prep_h.stop(s3));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_h, s3));
 
         MsmBuffers<Fq> buf_h, buf_l, buf_a, buf_b1;
         MsmBuffers<Fq2> buf_b2;
@@ -412,6 +400,7 @@ struct Impl {
         G16_TRY(fold_g1(0, sort_h.plan, out->h));
         G16_HIP_TRY(hipStreamSynchronize(s1));
         G16_HIP_TRY(hipStreamSynchronize(s2));
+        G16_HIP_TRY(hipStreamSynchronize(s3));
         const double t_end = now_ms();
 
         g16_timings& tm = ctx->tm;
@@ -430,6 +419,8 @@ struct Impl {
         for (int i = 0; i < 5; ++i) { tm.bucket_ms[i] = ctx->t_bucket[i].ms(); tm.bucket_pass_ms += tm.bucket_ms[i]; }
         tm.finish_ms = fold_ms;
         tm.total_ms = t_end - t_begin;
+        tm.window_bits = sort_z.plan.c;
+        tm.windows = sort_z.plan.W;
         return G16_OK;
     }
 
@@ -580,6 +571,8 @@ struct Impl {
         memcpy(out_affine, &res, sizeof(A));
         ctx->tm.bucket_pass_ms = ctx->t_bucket[0].ms();
         ctx->tm.bucket_ms[0] = ctx->tm.bucket_pass_ms;
+        ctx->tm.window_bits = ss.plan.c;
+        ctx->tm.windows = ss.plan.W;
         return G16_OK;
     }
 
@@ -775,6 +768,8 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lower = higher priority
     bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_wm, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 5; ++i)
@@ -794,16 +789,18 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamSynchronize(ctx->stream3);
     ctx->arena.release();
     ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy();
     for (int i = 0; i < 5; ++i) {
         ctx->t_bucket[i].destroy();
         (void)hipEventDestroy(ctx->ev_acc[i]); (void)hipEventDestroy(ctx->ev_done[i]); (void)hipEventDestroy(ctx->ev_msm_start[i]);
     }
-    (void)hipEventDestroy(ctx->ev_z); (void)hipEventDestroy(ctx->ev_h);
+    (void)hipEventDestroy(ctx->ev_z); (void)hipEventDestroy(ctx->ev_h); (void)hipEventDestroy(ctx->ev_wm);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
+    (void)hipStreamDestroy(ctx->stream3);
     delete ctx;
 }
 

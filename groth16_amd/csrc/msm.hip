@@ -41,6 +41,7 @@
 #include "internal.hpp"
 #include "msm_common.hpp"
 #include "fp30.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace g16 {
@@ -109,18 +110,21 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const
 
 // ---------------------------------------------------------------------------------------------
 // 1m/2m/4m. merged-window variants: every (point, window) digit is an entry of ONE bucket set of 2^(c-1) buckets, cut
-// into classes of B = 2^blog buckets.  Digit planes: a class byte (0xFF = zero digit) and a u16 (bucket in class | sign<<15)
-// per entry; workgroup (chunk, class q) walks all W planes of its point chunk and keeps the entries of class q.
-// Sorted entry = point | window << 26 | sign << 31.
+// into Q classes of B = 2^blog <= 2^15 buckets (what the LDS histogram holds).  Two levels:
+//   class_count_kernel / class_partition_kernel   entries -> Q contiguous class regions (block-local LDS cursors on top
+//                           of scanned per-(class, block) counts); an entry is a u16 key (bucket in class | sign << 15)
+//                           and a u32 tag (point | window << 26)
+//   bucket_count_merged_kernel / bucket_scatter_merged_kernel   per class: the same LDS counting sort as above, reading
+//                           the class region instead of a digit plane.   Sorted entry = point | window << 26 | sign << 31.
 // ---------------------------------------------------------------------------------------------
+static constexpr int CLASS_THREADS = 256;
+static constexpr int MAX_CLASSES = 16;
+
+// the thread's scalar, biased, as little-endian words in its column of sw
 template <class Fr>
-__global__ __launch_bounds__(256) void digits_merged_kernel(const Fr* __restrict__ scalars, uint64_t n, uint64_t pstride, PlanDev plan,
-                                                            uint32_t blog, uint8_t* __restrict__ cls, uint16_t* __restrict__ lop) {
-    __shared__ uint32_t sw[MSM_SWORDS][256];
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void biased_scalar(const Fr& sc, const PlanDev& plan, uint32_t (*sw)[CLASS_THREADS]) {
     uint32_t s[Fr::N];
-    scalars[i].to_canonical(s);
+    sc.to_canonical(s);
     uint64_t carry = 0;
     G16_UNROLL for (int k = 0; k < 10; ++k) {
         carry += (uint64_t)(k < Fr::N ? s[k] : 0u) + plan.K[k];
@@ -128,32 +132,67 @@ __global__ __launch_bounds__(256) void digits_merged_kernel(const Fr* __restrict
         carry >>= 32;
     }
     sw[10][threadIdx.x] = 0;
+}
+__device__ __forceinline__ uint32_t window_of(const uint32_t (*sw)[CLASS_THREADS], int w, int c) {
+    const int bit = w * c, word = bit >> 5, sh = bit & 31;
+    const uint64_t two = (uint64_t)sw[word][threadIdx.x] | ((uint64_t)sw[word + 1][threadIdx.x] << 32);
+    return (uint32_t)(two >> sh) & ((1u << c) - 1u);
+}
+
+// block_counts[q * gridDim.x + block] = entries of class q among this block's 256 points
+template <class Fr>
+__global__ __launch_bounds__(CLASS_THREADS) void class_count_kernel(const Fr* __restrict__ scalars, uint64_t n, PlanDev plan, uint32_t blog,
+                                                                    uint32_t Q, uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t sw[MSM_SWORDS][CLASS_THREADS];
+    __shared__ uint32_t cnt[MAX_CLASSES];
+    if (threadIdx.x < MAX_CLASSES) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * CLASS_THREADS + threadIdx.x;
+    if (i < n) {
+        biased_scalar(scalars[i], plan, sw);
+        for (int w = 0; w < plan.W; ++w) {
+            uint32_t key, neg;
+            if (digit_to_bucket(window_of(sw, w, plan.c), plan.c, &key, &neg)) atomicAdd(&cnt[key >> blog], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < Q) block_counts[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
+}
+
+template <class Fr>
+__global__ __launch_bounds__(CLASS_THREADS) void class_partition_kernel(const Fr* __restrict__ scalars, uint64_t n, PlanDev plan, uint32_t blog,
+                                                                        uint32_t Q, const uint32_t* __restrict__ block_off,
+                                                                        uint16_t* __restrict__ ent_key, uint32_t* __restrict__ ent_tag) {
+    __shared__ uint32_t sw[MSM_SWORDS][CLASS_THREADS];
+    __shared__ uint32_t cur[MAX_CLASSES];
+    if (threadIdx.x < Q) cur[threadIdx.x] = block_off[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * CLASS_THREADS + threadIdx.x;
+    if (i >= n) return;
+    biased_scalar(scalars[i], plan, sw);
     for (int w = 0; w < plan.W; ++w) {
-        const int bit = w * plan.c, word = bit >> 5, sh = bit & 31;
-        const uint64_t two = (uint64_t)sw[word][threadIdx.x] | ((uint64_t)sw[word + 1][threadIdx.x] << 32);
-        const uint32_t raw = (uint32_t)(two >> sh) & ((1u << plan.c) - 1u);
         uint32_t key, neg;
-        const bool nz = digit_to_bucket(raw, plan.c, &key, &neg);
-        cls[(uint64_t)w * pstride + i] = nz ? (uint8_t)(key >> blog) : (uint8_t)0xFF;
-        lop[(uint64_t)w * pstride + i] = (uint16_t)((key & ((1u << blog) - 1u)) | (neg << 15));
+        if (digit_to_bucket(window_of(sw, w, plan.c), plan.c, &key, &neg)) {
+            const uint32_t pos = atomicAdd(&cur[key >> blog], 1u);
+            ent_key[pos] = (uint16_t)((key & ((1u << blog) - 1u)) | (neg << 15));
+            ent_tag[pos] = (uint32_t)i | ((uint32_t)w << 26);
+        }
     }
 }
 
-static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_merged_kernel(const uint8_t* __restrict__ cls, const uint16_t* __restrict__ lop,
-                                                                           uint64_t n, uint64_t pstride, uint32_t chunk, int W, uint32_t B,
+// grid = (G, Q): workgroup (x, q) owns the tiles x, x + G, x + 2G, ... (SORT_THREADS entries each) of class region q
+static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_merged_kernel(const uint16_t* __restrict__ ent_key,
+                                                                           const uint32_t* __restrict__ class_off, uint32_t nb, uint32_t B,
                                                                            uint32_t* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     const uint32_t q = blockIdx.y;
+    const uint32_t lo = class_off[(uint64_t)q * nb], hi = class_off[(uint64_t)(q + 1) * nb];
+    if ((uint64_t)lo + (uint64_t)blockIdx.x * SORT_THREADS >= hi) return;
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) hist[b] = 0;
     __syncthreads();
-    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (int w = 0; w < W; ++w) {
-        const uint8_t* cp = cls + (uint64_t)w * pstride;
-        const uint16_t* lp = lop + (uint64_t)w * pstride;
-        for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS)
-            if (cp[p] == q) atomicAdd(&hist[lp[p] & 0x7fffu], 1u);
-    }
+    for (uint64_t p = (uint64_t)lo + blockIdx.x * SORT_THREADS + threadIdx.x; p < hi; p += (uint64_t)gridDim.x * SORT_THREADS)
+        atomicAdd(&hist[ent_key[p] & 0x7fffu], 1u);
     __syncthreads();
     uint32_t* out = counts + (uint64_t)q * B;
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
@@ -162,22 +201,20 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_merged_kerne
     }
 }
 
-static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_merged_kernel(const uint8_t* __restrict__ cls, const uint16_t* __restrict__ lop,
-                                                                             uint64_t n, uint64_t pstride, uint32_t chunk, int W, uint32_t B,
+static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_merged_kernel(const uint16_t* __restrict__ ent_key,
+                                                                             const uint32_t* __restrict__ ent_tag,
+                                                                             const uint32_t* __restrict__ class_off, uint32_t nb, uint32_t B,
                                                                              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                                                                              uint32_t* __restrict__ sorted) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     const uint32_t q = blockIdx.y;
+    const uint32_t lo = class_off[(uint64_t)q * nb], hi = class_off[(uint64_t)(q + 1) * nb];
+    if ((uint64_t)lo + (uint64_t)blockIdx.x * SORT_THREADS >= hi) return;
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) hist[b] = 0;
     __syncthreads();
-    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (int w = 0; w < W; ++w) {
-        const uint8_t* cp = cls + (uint64_t)w * pstride;
-        const uint16_t* lp = lop + (uint64_t)w * pstride;
-        for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS)
-            if (cp[p] == q) atomicAdd(&hist[lp[p] & 0x7fffu], 1u);
-    }
+    const uint64_t first = (uint64_t)lo + blockIdx.x * SORT_THREADS + threadIdx.x, step = (uint64_t)gridDim.x * SORT_THREADS;
+    for (uint64_t p = first; p < hi; p += step) atomicAdd(&hist[ent_key[p] & 0x7fffu], 1u);
     __syncthreads();
     const uint64_t qb = (uint64_t)q * B;
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
@@ -185,15 +222,10 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_merged_ker
         if (v) hist[b] = offsets[qb + b] + atomicAdd(&cursor[qb + b], v);
     }
     __syncthreads();
-    for (int w = 0; w < W; ++w) {
-        const uint8_t* cp = cls + (uint64_t)w * pstride;
-        const uint16_t* lp = lop + (uint64_t)w * pstride;
-        for (uint64_t p = lo + threadIdx.x; p < hi; p += SORT_THREADS)
-            if (cp[p] == q) {
-                const uint32_t d = lp[p];
-                const uint32_t pos = atomicAdd(&hist[d & 0x7fffu], 1u);
-                sorted[pos] = (uint32_t)p | ((uint32_t)w << 26) | ((d >> 15) << 31);
-            }
+    for (uint64_t p = first; p < hi; p += step) {
+        const uint32_t d = ent_key[p];
+        const uint32_t pos = atomicAdd(&hist[d & 0x7fffu], 1u);
+        sorted[pos] = ent_tag[p] | ((d >> 15) << 31);
     }
 }
 
@@ -625,12 +657,18 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     const uint32_t M = plan.buckets();
     const uint64_t nw = n * (uint64_t)plan.W;
     if (nw >= ((uint64_t)1 << 32)) return G16_ERR_BAD_LENGTH;
-    const uint64_t pstride = (n + 15) & ~(uint64_t)15;   // merged digit planes: one row per window
-    uint16_t* planes = nullptr;
-    uint8_t* cls = nullptr;
+    uint16_t* planes = nullptr;     // per-window plan: digit planes; merged plan: entry keys, class-partitioned
+    uint32_t* ent_tag = nullptr;    // merged plan: entry tags (point | window << 26), class-partitioned
+    uint32_t *class_cnt = nullptr, *class_off = nullptr;
     uint32_t *counts = nullptr, *cursor = nullptr, *nparts = nullptr, *block_sums = nullptr;
-    G16_TRY(arena.alloc_n(plan.merged ? pstride * plan.W + 16 : (nw ? nw : 1), &planes));
-    if (plan.merged) G16_TRY(arena.alloc_n(pstride * plan.W + 16, &cls));
+    const uint32_t nb = (uint32_t)((n + CLASS_THREADS - 1) / CLASS_THREADS), Q = (uint32_t)plan.groups;
+    G16_TRY(arena.alloc_n(nw ? nw : 1, &planes));
+    if (plan.merged) {
+        if (Q > MAX_CLASSES) return G16_ERR_INTERNAL;
+        G16_TRY(arena.alloc_n(nw ? nw : 1, &ent_tag));
+        G16_TRY(arena.alloc_n((size_t)Q * nb + 1, &class_cnt));
+        G16_TRY(arena.alloc_n((size_t)Q * nb + 1, &class_off));
+    }
     G16_TRY(arena.alloc_n((size_t)3 * M + 1, &counts));  // counts | scatter cursors | heavy count + list
     cursor = counts + M;
     out->heavy = counts + 2 * (size_t)M;
@@ -659,13 +697,30 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     }
     const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
     const uint32_t blog = (uint32_t)ilog2(plan.B);
+    const uint32_t lseg_log = (uint32_t)ilog2(plan.Lmax);
+    const uint32_t max_scan = std::max(M, plan.merged ? Q * nb : 0u);
+    G16_TRY(arena.alloc_n((size_t)(max_scan + SCAN_TILE - 1) / SCAN_TILE, &block_sums));
+    auto prefix_scan = [&](const uint32_t* vals, uint32_t* prefix, uint32_t count) -> int {
+        const uint32_t nblocks = (count + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, count, block_sums);
+        G16_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nblocks, count, prefix);
+        G16_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, count, block_sums, prefix);
+        G16_LAUNCH_CHECK();
+        return G16_OK;
+    };
+    // merged plan: ~2048 workgroups over the class regions (a class region may hold anything between nothing and all entries)
+    const unsigned gx = std::max(1u, std::min(2048u / Q, (unsigned)((nw + SORT_THREADS - 1) / SORT_THREADS)));
     if (n) {
         if (plan.merged) {
-            hipLaunchKernelGGL((digits_merged_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pstride, pd, blog,
-                               cls, planes);
+            hipLaunchKernelGGL((class_count_kernel<Fr>), dim3(nb), dim3(CLASS_THREADS), 0, st, d_scalars, n, pd, blog, Q, class_cnt);
             G16_LAUNCH_CHECK();
-            hipLaunchKernelGGL(bucket_count_merged_kernel, dim3(nchunks, plan.groups), dim3(SORT_THREADS), lds, st, cls, planes, n, pstride,
-                               plan.chunk, plan.W, plan.B, counts);
+            G16_TRY(prefix_scan(class_cnt, class_off, Q * nb));
+            hipLaunchKernelGGL((class_partition_kernel<Fr>), dim3(nb), dim3(CLASS_THREADS), 0, st, d_scalars, n, pd, blog, Q, class_off, planes,
+                               ent_tag);
+            G16_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bucket_count_merged_kernel, dim3(gx, Q), dim3(SORT_THREADS), lds, st, planes, class_off, nb, plan.B, counts);
         } else {
             hipLaunchKernelGGL((digits_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pd, planes);
             G16_LAUNCH_CHECK();
@@ -674,25 +729,14 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
         }
         G16_LAUNCH_CHECK();
     }
-    const uint32_t nblocks = (M + SCAN_TILE - 1) / SCAN_TILE, lseg_log = (uint32_t)ilog2(plan.Lmax);
-    G16_TRY(arena.alloc_n((size_t)nblocks, &block_sums));
-    auto prefix_scan = [&](const uint32_t* vals, uint32_t* prefix) -> int {
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, M, block_sums);
-        G16_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nblocks, M, prefix);
-        G16_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, M, block_sums, prefix);
-        G16_LAUNCH_CHECK();
-        return G16_OK;
-    };
-    G16_TRY(prefix_scan(counts, out->offsets));
+    G16_TRY(prefix_scan(counts, out->offsets, M));
     hipLaunchKernelGGL(bucket_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, out->offsets, M, lseg_log, nparts, out->heavy);
     G16_LAUNCH_CHECK();
-    G16_TRY(prefix_scan(nparts, out->task_off));
+    G16_TRY(prefix_scan(nparts, out->task_off, M));
     if (n) {
         if (plan.merged)
-            hipLaunchKernelGGL(bucket_scatter_merged_kernel, dim3(nchunks, plan.groups), dim3(SORT_THREADS), lds, st, cls, planes, n, pstride,
-                               plan.chunk, plan.W, plan.B, out->offsets, cursor, out->sorted);
+            hipLaunchKernelGGL(bucket_scatter_merged_kernel, dim3(gx, Q), dim3(SORT_THREADS), lds, st, planes, ent_tag, class_off, nb, plan.B,
+                               out->offsets, cursor, out->sorted);
         else
             hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
                                out->offsets, cursor, out->sorted);

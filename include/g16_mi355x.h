@@ -113,6 +113,8 @@ typedef struct {
     double total_ms;
     double bucket_pass_ms; /* sum over the 5 MSMs of the bucket-accumulation kernel */
     double bucket_ms[5];   /* that kernel per MSM: h, l, a, b_g1 (G1 kernel), b_g2 (G2 kernel); HIP events on the ctx stream */
+    double window_bits;    /* Pippenger window size c of the witness MSMs in the last call ... */
+    double windows;        /* ... and their window count W: a bucket pass folds (bases in the shard) * W points */
 } g16_timings;
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out);
