@@ -363,21 +363,28 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
     }
     uint32_t b = lo, b_first = offsets[b], b_end = offsets[b + 1];
     Acc30<F30> acc = Acc30<F30>::identity();
-    // software pipeline: the (index -> base point) gather of entry e+1 is issued before the ~20k-instruction
-    // addition of entry e, so its two dependent HBM latencies hide under arithmetic
+    // software pipeline: the base point of entry e+1 is gathered (and the sorted word of entry e+2 loaded) before the
+    // ~20k-instruction addition of entry e, so the HBM latencies hide under arithmetic.  (Touching the cache lines of
+    // entry e+2 with direct-to-LDS loads was tried for the window tables' wider gather: 25 % slower.)
     uint32_t v_next = 0;
     F30 px_next = F30::zero(), py_next = F30::zero();
     bool ok_next = false;
-    auto fetch = [&](uint32_t e) {
-        v_next = sorted[e];
+    auto decode = [&](uint32_t v, int64_t* at) -> bool {
         // per-window plan: entry = point | sign<<31 ; merged plan: point | window<<26 | sign<<31, base = table[window][point]
-        const uint32_t pt = merged ? (v_next & 0x3ffffffu) : (v_next & 0x7fffffffu);
-        const uint64_t row = merged ? (uint64_t)((v_next >> 26) & 31u) * base_count : 0;
+        const uint32_t pt = merged ? (v & 0x3ffffffu) : (v & 0x7fffffffu);
+        const uint64_t row = merged ? (uint64_t)((v >> 26) & 31u) * base_count : 0;
         const int64_t idx = (int64_t)pt + shift;
-        ok_next = idx >= 0 && (uint64_t)idx < base_count;
-        if (ok_next) ok_next = F30::load_point(bases, (int64_t)(row + (uint64_t)idx), px_next, py_next);
+        *at = (int64_t)row + idx;
+        return idx >= 0 && (uint64_t)idx < base_count;
     };
-    fetch(start);
+    auto fetch = [&](uint32_t v) {
+        v_next = v;
+        int64_t at;
+        ok_next = decode(v, &at);
+        if (ok_next) ok_next = F30::load_point(bases, at, px_next, py_next);
+    };
+    fetch(sorted[start]);
+    uint32_t v_fetch = start + 1 < end ? sorted[start + 1] : 0u;   // entry e+1's word, loaded one iteration early
     for (uint32_t e = start; e < end; ++e) {
         if (e == b_end) {  // crossed into the next non-empty bucket: flush this segment's share of bucket b
             acc.store_raw(&partials[slot_off[b] + (t - (b_first >> lseg_log))]);
@@ -389,16 +396,16 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         const F30 px = px_next;
         F30 py = py_next;
         const bool ok = ok_next;
-        if constexpr (F30::ACC_PREFETCH) {
-            if (e + 1 < end) fetch(e + 1);
-        }
+        auto advance = [&]() {
+            if (e + 1 < end) fetch(v_fetch);
+            v_fetch = e + 2 < end ? sorted[e + 2] : 0u;
+        };
+        if constexpr (F30::ACC_PREFETCH) advance();
         if (ok) {
             if (v >> 31) py = py.neg2();
             acc.add_affine(px, py);
         }
-        if constexpr (!F30::ACC_PREFETCH) {
-            if (e + 1 < end) fetch(e + 1);
-        }
+        if constexpr (!F30::ACC_PREFETCH) advance();
     }
     acc.store_raw(&partials[slot_off[b] + (t - (b_first >> lseg_log))]);
 }
