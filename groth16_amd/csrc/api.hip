@@ -62,6 +62,8 @@ struct g16_ctx {
     hipStream_t stream;   // bucket passes, digit/sort
     hipStream_t stream2;  // witness digit/sort pass, then the latency-bound reductions underneath the bucket passes
     hipStream_t stream3;  // h's digit/sort pass, underneath the first bucket pass
+    hipStream_t red[5];   // one stream per MSM for its reductions: they are chains of dependent additions in a few waves
+                          // (G2: ~9 ms), so five of them side by side end sooner than one after the other
     Arena arena;
     g16_timings tm;
     EventTimer t_wm, t_prep_h, t_prep_z, t_bucket[5];
@@ -346,16 +348,22 @@ struct Impl {
         }
         char* pin = static_cast<char*>(ctx->pinned);
         if (sort_z.plan.outputs() > 96 || sort_h.plan.outputs() > 96) return G16_ERR_INTERNAL;
-        // bucket pass on stream 1; reduction + copy-out on stream 2
+        // bucket pass on stream 1; reduction + copy-out underneath the following passes.  A reduction is a chain of
+        // dependent additions in a few waves (G1 ~1.5 ms, G2 ~9 ms, independent of the shard size).  Long passes (whole
+        // key): all reductions queue on stream 2 -- side by side they take more from the passes than they give back
+        // (measured 88.5 vs 82.0 ms at 2^22).  Short passes (a 1/4 .. 1/8 shard): one stream per MSM, otherwise the
+        // queue of reductions outlasts the passes (25.6 -> 23.0 ms per rank at 8 shards).
+        const bool short_passes = (uint64_t)pk->a_count * (uint64_t)sort_z.plan.W < 20000000ull;
         auto run_msm = [&](int k, auto* bases, int64_t shift, uint64_t count, const ScalarSort& ss, auto* buf) -> int {
             typedef typename std::remove_pointer<decltype(buf)>::type Buf;
+            hipStream_t sr = short_passes ? ctx->red[k] : s2;
             G16_HIP_TRY(hipEventRecord(ctx->ev_msm_start[k], s1));
             G16_TRY((msm_bucket_pass(bases, shift, count, ss, ctx->arena, s1, buf, &ctx->t_bucket[k])));
             G16_HIP_TRY(hipEventRecord(ctx->ev_acc[k], s1));
-            G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_acc[k], 0));
-            G16_TRY((msm_reduce(*buf, ss, s2)));
-            G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf->window_sums, sizeof(*Buf().window_sums) * ss.plan.outputs(), hipMemcpyDeviceToHost, s2));
-            G16_HIP_TRY(hipEventRecord(ctx->ev_done[k], s2));
+            G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_acc[k], 0));
+            G16_TRY((msm_reduce(*buf, ss, sr)));
+            G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf->window_sums, sizeof(*Buf().window_sums) * ss.plan.outputs(), hipMemcpyDeviceToHost, sr));
+            G16_HIP_TRY(hipEventRecord(ctx->ev_done[k], sr));
             return G16_OK;
         };
 
@@ -401,6 +409,7 @@ struct Impl {
         G16_HIP_TRY(hipStreamSynchronize(s1));
         G16_HIP_TRY(hipStreamSynchronize(s2));
         G16_HIP_TRY(hipStreamSynchronize(s3));
+        for (int k = 0; k < 5; ++k) G16_HIP_TRY(hipStreamSynchronize(ctx->red[k]));
         const double t_end = now_ms();
 
         g16_timings& tm = ctx->tm;
@@ -769,6 +778,11 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
     bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->red[0], hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->red[1], hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->red[2], hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->red[3], hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->red[4], hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_wm, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming) == hipSuccess;
@@ -790,6 +804,7 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream3);
+    for (int i = 0; i < 5; ++i) (void)hipStreamSynchronize(ctx->red[i]);
     ctx->arena.release();
     ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy();
     for (int i = 0; i < 5; ++i) {
@@ -801,6 +816,7 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream3);
+    for (int i = 0; i < 5; ++i) (void)hipStreamDestroy(ctx->red[i]);
     delete ctx;
 }
 

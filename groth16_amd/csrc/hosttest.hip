@@ -265,6 +265,29 @@ struct SelfTest {
                 if (!(other.to_std().to_affine() == ro.to_affine())) return 2000 + round;
                 uint32_t kw[1] = {12345u + (uint32_t)round};
                 if (!(acc.mul_small(kw[0]).to_std().to_affine() == ref.mul_bits(kw, 32).to_affine())) return 2100 + round;
+                {   // the reductions' use of the Karatsuba accumulator: raw-limb hand-over from the bucket pass, full
+                    // additions, doublings and small multiples chained on lazy values
+                    typedef AccRaw<F230> Raw;
+                    Raw slot;
+                    acc.store_raw(&slot);
+                    Acc30<FK> k1 = Acc30<FK>::load_raw(slot), k2 = Acc30<FK>::load_raw(slot);
+                    G2X r1 = ref, r2 = ref;
+                    for (int j = 0; j < 6; ++j) {
+                        k1.dbl(); r1 = r1.dbl();
+                        k1.add(k2); r1.add(r2);
+                        k2.add(k1); r2.add(r1);
+                        Raw tmp;
+                        k2.store_raw(&tmp);
+                        k2 = Acc30<FK>::load_raw(tmp);
+                        if (!(k1.to_std().to_affine() == r1.to_affine())) return 4000 + round * 10 + j;
+                        if (!(k2.to_std().to_affine() == r2.to_affine())) return 4100 + round * 10 + j;
+                    }
+                    Acc30<FK> same = k1;
+                    same.add(k1); r2 = r1; r2.add(r1);          // equal operands -> doubling branch
+                    if (!(same.to_std().to_affine() == r2.to_affine())) return 4200 + round;
+                    if (!(k1.mul_small(kw[0]).to_std().to_affine() == r1.mul_bits(kw, 32).to_affine())) return 4300 + round;
+                    if (!(k1.mul_small(32760u).to_std().to_affine() == r1.mul_bits((const uint32_t[]){32760u}, 16).to_affine())) return 4400 + round;
+                }
             }
         }
         return 0;

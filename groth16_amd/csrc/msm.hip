@@ -426,7 +426,12 @@ __global__ void convert_bases30_kernel(Affine<F>* __restrict__ pts, uint64_t n) 
 template <class F> struct Lazy30;   // field used by the reduction kernels (and by the G1 bucket pass)
 template <class P> struct Lazy30<Fp<P>> { typedef Fp30<P> type; typedef Fp30<P> acc_type; };
 template <class P> struct Lazy30<Fp2<P>> {
-    typedef Fp2x30<P> type;
+#if defined(G16_G2_REDUCE_FP2K30)
+    typedef Fp2k30<P> type;       // register-passed Karatsuba (same raw limb layout): less scratch, but one wave per SIMD --
+                                  // measured slower for the reductions (82.1 vs 80.8 ms per proof at 2^22, same box)
+#else
+    typedef Fp2x30<P> type;       // reductions: 4-product lazy Fq2 with out-of-line products
+#endif
 #if defined(G16_G2_ACC_FP2X30)
     typedef Fp2x30<P> acc_type;
 #elif defined(G16_G2_ACC_FP2K30)
@@ -445,10 +450,10 @@ static constexpr int HEAVY_THREADS = 128;
 static constexpr int HEAVY_BLOCKS = 512;
 
 template <class F30>
-__global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(AccRaw<F30>* __restrict__ partials, const uint32_t* __restrict__ slot_off,
+__global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(AccRaw<typename F30::Raw>* __restrict__ partials, const uint32_t* __restrict__ slot_off,
                                                                      const uint32_t* __restrict__ heavy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    AccRaw<F30>* sh = reinterpret_cast<AccRaw<F30>*>(smem);
+    AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
     const uint32_t nheavy = heavy[0], tid = threadIdx.x;
     for (uint32_t i = blockIdx.x; i < nheavy; i += gridDim.x) {
         const uint32_t b = heavy[1 + i];
@@ -474,9 +479,9 @@ __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(AccRaw<F30>
 // 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
 // ---------------------------------------------------------------------------------------------
 template <class F30>
-__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw<F30>* __restrict__ partials,
+__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw<typename F30::Raw>* __restrict__ partials,
                                                                     const uint32_t* __restrict__ slot_off, uint32_t B, int W, uint32_t G,
-                                                                    AccRaw<F30>* __restrict__ chunk_out, AccRaw<F30>* __restrict__ chunk_sum) {
+                                                                    AccRaw<typename F30::Raw>* __restrict__ chunk_out, AccRaw<typename F30::Raw>* __restrict__ chunk_sum) {
     const uint32_t cpw = B / G;
     const uint32_t t = blockIdx.x * RED_THREADS + threadIdx.x;
     if (t >= cpw * (uint32_t)W) return;
@@ -497,10 +502,10 @@ __global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw
 }
 
 template <class F30>
-__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw<F30>* __restrict__ chunk_out, uint32_t cpw,
+__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw<typename F30::Raw>* __restrict__ chunk_out, uint32_t cpw,
                                                                     XYZZ<typename F30::Std>* __restrict__ window_sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    AccRaw<F30>* sh = reinterpret_cast<AccRaw<F30>*>(smem);
+    AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     Acc30<F30> acc = Acc30<F30>::identity();
     for (uint32_t j = tid; j < cpw; j += WIN_THREADS) acc.add(Acc30<F30>::load_raw(chunk_out[(uint64_t)w * cpw + j]));
@@ -756,7 +761,7 @@ template <class F>
 int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena, hipStream_t st,
                     MsmBuffers<F>* out, EventTimer* bucket_timer) {
     typedef typename Lazy30<F>::acc_type F30;
-    typedef AccRaw<typename Lazy30<F>::type> Raw;
+    typedef AccRaw<typename Lazy30<F>::type::Raw> Raw;
     const MsmPlan& plan = ss.plan;
     const uint32_t M = plan.buckets();
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
@@ -782,7 +787,7 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
 template <class F>
 int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     typedef typename Lazy30<F>::type F30;
-    typedef AccRaw<F30> Raw;
+    typedef AccRaw<typename F30::Raw> Raw;
     const MsmPlan& plan = ss.plan;
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
