@@ -35,8 +35,8 @@
 // of n*16 points (BLS12-381 and BN254 scalars); the 2^19 buckets are cut into 16 classes of 2^15 for the LDS histogram
 // (*_merged_kernel below), and the reductions treat a class like a window.  Costs 13x the key's memory (31 GB at 2^22
 // constraints on BLS12-381 -- HBM capacity is what this GPU has to spare) and a one-off table build at load time.
-// Roofline: step 5 reads ~N*W*(sizeof(Affine)+4) bytes (8.8 GB measured at 2^22, G1) but spends ~10 field
-// products (~3400 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
+// Roofline: step 5 reads ~N*W*(sizeof(Affine)+4) bytes (7.7 GB measured at 2^22, G1, merged windows) but spends ~10
+// field products (~3400 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
 // bytes/s it sustains is reported against the 8 TB/s roofline by bench.py regardless.
 #include "internal.hpp"
 #include "msm_common.hpp"
@@ -50,7 +50,10 @@ static constexpr int SORT_THREADS = 1024;
 static constexpr int ACC_THREADS = 128;
 static constexpr int RED_THREADS = 64;
 static constexpr int WIN_THREADS = 256;  // lanes of the per-window reduction
-static constexpr uint32_t REDUCE_G = 8;   // buckets per lane in the bucket reduction
+#ifndef G16_REDUCE_G
+#define G16_REDUCE_G 8
+#endif
+static constexpr uint32_t REDUCE_G = G16_REDUCE_G;   // buckets per lane in the bucket reduction
 
 struct PlanDev {
     int c, W;
