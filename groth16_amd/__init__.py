@@ -11,12 +11,13 @@ Reference interface mirrored (paths relative to /root/reference):
   LibsnarkReduction.witness_map_from_matrices        src/r1cs_to_qap.rs:172-235
   ProvingKey / Proof / ConstraintMatrices            src/data_structures.rs:8-16,125-143
   SynthesisError.PolynomialDegreeTooLarge            src/r1cs_to_qap.rs:178-179
+  Groth16.generate_parameters_with_qap               src/generator.rs:47-208 (matrices form)
 """
-from .binding import (G16Error, Lib, PolynomialDegreeTooLarge, SynthesisError, lib, FQ_LIMBS, CURVE_ID)  # noqa: F401
+from .binding import (G16Error, Lib, PolynomialDegreeTooLarge, SynthesisError, UnexpectedIdentity, lib, FQ_LIMBS, CURVE_ID)  # noqa: F401
 from .groth16 import (ConstraintMatrices, Groth16, LibsnarkReduction, Proof, ProvingKey, ShardedProver, finalize_host,  # noqa: F401
                       shard_ranges)
 
 __all__ = [
     "Groth16", "LibsnarkReduction", "ConstraintMatrices", "ProvingKey", "Proof", "ShardedProver", "G16Error", "SynthesisError",
-    "PolynomialDegreeTooLarge", "lib",
+    "PolynomialDegreeTooLarge", "UnexpectedIdentity", "lib",
 ]

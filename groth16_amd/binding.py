@@ -31,6 +31,10 @@ class PolynomialDegreeTooLarge(SynthesisError):
     pass
 
 
+class UnexpectedIdentity(SynthesisError):
+    """gamma or delta is zero (generator.rs:110-111)"""
+
+
 class QueryC(C.Structure):
     _fields_ = [("points", C.c_void_p), ("count", C.c_uint64), ("start", C.c_uint64)]
 
@@ -46,6 +50,15 @@ class PkViewC(C.Structure):
 
 class CsrViewC(C.Structure):
     _fields_ = [("row_ptr", u64p), ("col", u32p), ("val", u64p)]
+
+
+class ToxicWasteC(C.Structure):
+    _fields_ = [(n, C.c_uint64 * 4) for n in ("alpha", "beta", "gamma", "delta", "t")]
+
+
+class ParamsViewC(C.Structure):
+    _fields_ = [(n, u64p) for n in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2", "gamma_g2", "gamma_abc_g1")] + \
+               [(n, C.c_void_p) for n in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")] + [("flags", C.c_uint32)]
 
 
 class ProofC(C.Structure):
@@ -72,7 +85,8 @@ EXPORTS = [
     "g16_ctx_create", "g16_ctx_destroy", "g16_ctx_stream", "g16_pk_load", "g16_pk_free", "g16_circuit_load", "g16_circuit_free",
     "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_finalize_host", "g16_get_timings", "g16_witness_map",
     "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
-    "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version",
+    "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version", "g16_generate_parameters",
+    "g16_host_qap_evaluations",
 ]
 
 
@@ -129,6 +143,9 @@ class Lib:
         c.g16_host_group_op.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
         c.g16_host_selftest.argtypes = [C.c_int, C.c_uint64, C.c_int]
         c.g16_host_msm_model.argtypes = [C.c_int, C.c_int, u64p, u64p, C.c_uint64, C.c_int, u64p]
+        c.g16_generate_parameters.argtypes = [C.c_void_p, C.POINTER(CsrViewC), C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(ToxicWasteC),
+                                              u64p, u64p, C.POINTER(ParamsViewC)]
+        c.g16_host_qap_evaluations.argtypes = [C.c_int, C.POINTER(CsrViewC), C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p, u64p, u64p, u64p]
 
     def check(self, status: int):
         if status == 0:
@@ -139,6 +156,8 @@ class Lib:
             msg += " | " + detail
         if status == 1:
             raise PolynomialDegreeTooLarge(status, msg)
+        if status == 8:
+            raise UnexpectedIdentity(status, msg)
         raise G16Error(status, msg)
 
     def version(self) -> str:

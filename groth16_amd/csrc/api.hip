@@ -945,6 +945,37 @@ int g16_host_msm_model(int curve, int g2, const uint64_t* bases, const uint64_t*
     G16_DISPATCH(curve, I::template msm_model<typename I::Fq2>(bases, scalars, n, c, out_affine));
 }
 
+int g16_generate_parameters(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints, uint64_t num_variables,
+                            const g16_toxic_waste* tw, const uint64_t* g1_generator, const uint64_t* g2_generator, const g16_params_view* out) {
+    if (!ctx || !abc || !tw || !g1_generator || !g2_generator || !out) return G16_ERR_BAD_ARG;
+    if (!out->alpha_g1 || !out->beta_g1 || !out->delta_g1 || !out->beta_g2 || !out->delta_g2 || !out->gamma_g2) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    try {
+        if (ctx->curve == G16_BLS12_381)
+            return generate_parameters_device<Bls12_381>(ctx->stream, ctx->arena, abc, num_inputs, num_constraints, num_variables, tw,
+                                                         g1_generator, g2_generator, out);
+        if (ctx->curve == G16_BN254)
+            return generate_parameters_device<Bn254>(ctx->stream, ctx->arena, abc, num_inputs, num_constraints, num_variables, tw,
+                                                     g1_generator, g2_generator, out);
+    } catch (const std::bad_alloc&) {
+        return G16_ERR_OOM;
+    }
+    return G16_ERR_BAD_ARG;
+}
+
+int g16_host_qap_evaluations(int curve, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints, uint64_t num_variables,
+                             const uint64_t t[4], uint64_t* a_out, uint64_t* b_out, uint64_t* c_out, uint64_t zt_out[4]) {
+    if (!abc || !t || !a_out || !b_out || !c_out || !zt_out) return G16_ERR_BAD_ARG;
+    try {
+        if (curve == G16_BLS12_381)
+            return qap_evaluations_host<Bls12_381>(abc, num_inputs, num_constraints, num_variables, t, a_out, b_out, c_out, zt_out);
+        if (curve == G16_BN254) return qap_evaluations_host<Bn254>(abc, num_inputs, num_constraints, num_variables, t, a_out, b_out, c_out, zt_out);
+    } catch (const std::bad_alloc&) {
+        return G16_ERR_OOM;
+    }
+    return G16_ERR_BAD_ARG;
+}
+
 const char* g16_strerror(int status) {
     switch (status) {
         case G16_OK: return "ok";
@@ -955,6 +986,7 @@ const char* g16_strerror(int status) {
         case G16_ERR_OOM: return "out of memory";
         case G16_ERR_NO_DEVICE: return "no HIP device";
         case G16_ERR_INTERNAL: return "internal error";
+        case G16_ERR_UNEXPECTED_IDENTITY: return "unexpected identity: gamma or delta is zero";
         default: return "unknown status";
     }
 }

@@ -169,6 +169,14 @@ template <class F> XYZZ<F> fold_windows(const XYZZ<F>* window_sums, const MsmPla
 // (what convert_bases leaves); src holds standard-form affine points and is not modified
 template <class F> int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine<F>* d_table, hipStream_t st);
 
+// ---- CRS generation (setup.hip) -------------------------------------------------------------------
+template <class C>
+int generate_parameters_device(hipStream_t st, Arena& arena, const g16_csr_view abc[3], uint64_t ni, uint64_t nc, uint64_t nv,
+                               const g16_toxic_waste* tw, const uint64_t* g1_gen, const uint64_t* g2_gen, const g16_params_view* out);
+template <class C>
+int qap_evaluations_host(const g16_csr_view abc[3], uint64_t ni, uint64_t nc, uint64_t nv, const uint64_t* t, uint64_t* a_out, uint64_t* b_out,
+                         uint64_t* c_out, uint64_t* zt_out);
+
 // ---- synthetic generators (synth.hip) -----------------------------------------------------------
 template <class C> int synth_bases_device(int g2, uint64_t seed, uint64_t first, uint64_t n, void* out_dev, hipStream_t st);
 

@@ -13,7 +13,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .binding import (CURVE_ID, FQ_LIMBS, CsrViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC, lib, ptr32, ptr64, u64p)
+from .binding import (CURVE_ID, FQ_LIMBS, CsrViewC, ParamsViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC, ToxicWasteC, lib, ptr32,
+                      ptr64, u64p)
 
 _MODULUS_R = {
     "bls12_381": 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
@@ -67,6 +68,9 @@ class ProvingKey:
     b_g2_query: np.ndarray
     h_query: np.ndarray
     l_query: np.ndarray
+    # the rest of the VerifyingKey (data_structures.rs:28-41); the prover never reads these
+    gamma_g2: Optional[np.ndarray] = None
+    gamma_abc_g1: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -218,6 +222,33 @@ class Groth16:
 
     def __exit__(self, *exc):
         self.close()
+
+    # -- generator.rs:47-208 ----------------------------------------------------------------
+    def generate_parameters_with_qap(self, matrices: ConstraintMatrices, alpha: np.ndarray, beta: np.ndarray, gamma: np.ndarray,
+                                     delta: np.ndarray, g1_generator: np.ndarray, g2_generator: np.ndarray, t: np.ndarray) -> ProvingKey:
+        """Groth16::generate_parameters_with_qap on the matrices of an already synthesised circuit.  Arguments as the reference's
+        (toxic waste as Fr limbs, generators as affine points); `t` is what the reference draws from its rng
+        (domain.sample_element_outside_domain, generator.rs:90)."""
+        L = FQ_LIMBS[self.curve]
+        ni, nv = matrices.num_instance_variables, matrices.num_instance_variables + matrices.num_witness_variables
+        need, n = matrices.num_constraints + ni, 1
+        while n < need:
+            n <<= 1
+        g1 = lambda k: np.zeros((k, 2 * L), dtype=np.uint64)  # noqa: E731
+        g2 = lambda k: np.zeros((k, 4 * L), dtype=np.uint64)  # noqa: E731
+        pk = ProvingKey(self.curve, g1(1), g1(1), g1(1), g2(1), g2(1), g1(nv), g1(nv), g2(nv), g1(n - 1), g1(nv - ni), g2(1), g1(ni))
+        tw = ToxicWasteC()
+        for name, v in (("alpha", alpha), ("beta", beta), ("gamma", gamma), ("delta", delta), ("t", t)):
+            getattr(tw, name)[:] = [int(x) for x in _c(v).reshape(4)]
+        vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        out = ParamsViewC(ptr64(pk.alpha_g1), ptr64(pk.beta_g1), ptr64(pk.delta_g1), ptr64(pk.beta_g2), ptr64(pk.delta_g2), ptr64(pk.gamma_g2),
+                          ptr64(pk.gamma_abc_g1), vp(pk.a_query), vp(pk.b_g1_query), vp(pk.b_g2_query), vp(pk.h_query), vp(pk.l_query), 0)
+        views = (CsrViewC * 3)(*[CsrViewC(ptr64(np.ascontiguousarray(x[0], dtype=np.uint64)), ptr32(np.ascontiguousarray(x[1], dtype=np.uint32)),
+                                          ptr64(_c(x[2]))) for x in (matrices.a, matrices.b, matrices.c)])
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_generate_parameters(self._ctx.handle, views, ni, matrices.num_constraints, nv, C.byref(tw),
+                                              ptr64(_c(g1_generator).reshape(-1)), ptr64(_c(g2_generator).reshape(-1)), C.byref(out)))
+        return pk
 
     # -- prover.rs:26-51 -------------------------------------------------------------------
     def create_proof_with_reduction_and_matrices(self, pk: ProvingKey, r: np.ndarray, s: np.ndarray, matrices: ConstraintMatrices,

@@ -45,7 +45,8 @@ typedef enum {
     G16_ERR_HIP = 4,
     G16_ERR_OOM = 5,
     G16_ERR_NO_DEVICE = 6,
-    G16_ERR_INTERNAL = 7
+    G16_ERR_INTERNAL = 7,
+    G16_ERR_UNEXPECTED_IDENTITY = 8 /* SynthesisError::UnexpectedIdentity: gamma or delta is zero (generator.rs:110-111) */
 } g16_status;
 
 typedef enum { G16_BLS12_381 = 0, G16_BN254 = 1 } g16_curve;
@@ -170,6 +171,38 @@ int g16_synth_bases(g16_ctx* ctx, int g2, uint64_t seed, uint64_t first, uint64_
  * Host buffers: z_out (2^k+1) Fr, row_ptr n_c+1, colA/B/C n_c each, val n_c Fr (all one, shared). */
 int g16_synth_circuit(int curve, int k, uint64_t seed, uint64_t* z_out, uint64_t* row_ptr, uint32_t* colA,
                       uint32_t* colB, uint32_t* colC, uint64_t* val);
+
+/* ---- CRS generation: Groth16::generate_parameters_with_qap, src/generator.rs:47-208 ----
+ * The matrices-level form, like g16_prove: the caller synthesises the circuit (generator.rs:62-76) and passes
+ * cs.to_matrices().  The reference draws t from the rng (generator.rs:90); here it comes with the rest of the toxic
+ * waste so that a run can be replayed.  Scalar work (Lagrange coefficients at t, a/b/c(t), l, gamma_abc, h scalars:
+ * r1cs_to_qap.rs:120-170, 236-246) runs on the host, the ~5n fixed-base multiplications on the GPU. */
+typedef struct {
+    uint64_t alpha[4], beta[4], gamma[4], delta[4], t[4]; /* Fr, arkworks Montgomery limbs */
+} g16_toxic_waste;
+
+#define G16_PARAMS_DEVICE_PTRS 1u /* the five query arrays below are device memory of the ctx's GPU */
+
+typedef struct {
+    uint64_t *alpha_g1, *beta_g1, *delta_g1; /* one G1 affine each, host memory                                   */
+    uint64_t *beta_g2, *delta_g2, *gamma_g2; /* one G2 affine each, host memory                                   */
+    uint64_t* gamma_abc_g1;                  /* num_inputs G1, host memory (VerifyingKey, data_structures.rs:39)  */
+    uint64_t *a_query, *b_g1_query;          /* num_variables G1 each; entry 0 belongs to the constant-one variable */
+    uint64_t* b_g2_query;                    /* num_variables G2                                                  */
+    uint64_t* h_query;                       /* domain_size - 1 G1                                                */
+    uint64_t* l_query;                       /* num_variables - num_inputs G1                                     */
+    uint32_t flags;
+} g16_params_view;
+
+/* status: G16_ERR_DEGREE_TOO_LARGE as in the prover; G16_ERR_UNEXPECTED_IDENTITY for gamma == 0 or delta == 0;
+ * G16_ERR_BAD_ARG if t lies in the evaluation domain (sample_element_outside_domain never returns such a t) */
+int g16_generate_parameters(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints,
+                            uint64_t num_variables, const g16_toxic_waste* toxic_waste, const uint64_t* g1_generator,
+                            const uint64_t* g2_generator, const g16_params_view* out);
+/* CPU only: LibsnarkReduction::instance_map_with_evaluation (r1cs_to_qap.rs:120-170) -- a, b, c: num_variables Fr each */
+int g16_host_qap_evaluations(int curve, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints,
+                             uint64_t num_variables, const uint64_t t[4], uint64_t* a_out, uint64_t* b_out,
+                             uint64_t* c_out, uint64_t zt_out[4]);
 
 /* ---- host-side arithmetic self-test hooks (CPU; used by the `not gpu` tests) ----
  * The same field / group code the kernels use, compiled for the host.
