@@ -3,9 +3,10 @@
 
 A "step" is one Groth16 proof of the synthetic R1CS SYN(k) (Fibonacci product chain,
 n_c = 2^k - 2 constraints, FFT domain exactly 2^k; default k = 22 = BASELINE.json configs[2], the full
-prover: witness-map NTTs + h/l/a/b_g1 G1 MSMs + the b_g2 G2 MSM) over a synthetic-bases proving key
-(distinct non-identity points generated on the GPU), with the witness, the CSR matrices and the proving
-key already resident in HBM when the timed region starts -- the scope of
+prover: witness-map NTTs + h/l/a/b_g1 G1 MSMs + the b_g2 G2 MSM) over a VALID proving key generated on the
+GPU from seeded toxic waste (g16_generate_parameters = Groth16::generate_parameters_with_qap; --key synthetic
+falls back to distinct non-identity points), with the witness, the CSR matrices and the proving key already
+resident in HBM when the timed region starts -- the scope of
 Groth16::create_proof_with_reduction_and_matrices (/root/reference/src/prover.rs:26-51).
 
 N > 1 (one process per GPU, launched by torch.distributed.run): the MSM base arrays are sharded over
@@ -32,7 +33,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import groth16_amd as g  # noqa: E402
-from groth16_amd.binding import (CURVE_ID, FQ_LIMBS, CsrViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC, ptr32, ptr64)  # noqa: E402
+from groth16_amd.binding import (CURVE_ID, FQ_LIMBS, CsrViewC, ParamsViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC, ToxicWasteC,  # noqa: E402
+                                 ptr32, ptr64)
+from groth16_amd.groth16 import _MODULUS_R  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -42,10 +45,11 @@ def shard_range(n, idx, cnt):
 
 
 class DeviceProver:
-    """SYN(k) circuit + synthetic-bases proving-key shard, everything resident on one GPU."""
+    """SYN(k) circuit + proving-key shard, everything resident on one GPU.  key = "valid": the CRS of the circuit, generated
+    on the GPU from seeded toxic waste; "synthetic": distinct non-identity points (any points give the same prover work)."""
 
-    def __init__(self, curve, k, seed, rank, world, device):
-        self.curve, self.k, self.rank, self.world = curve, k, rank, world
+    def __init__(self, curve, k, seed, rank, world, device, key="valid"):
+        self.curve, self.k, self.rank, self.world, self.key = curve, k, rank, world, key
         self.lib = g.lib()
         c = self.lib.c
         L = FQ_LIMBS[curve]
@@ -83,18 +87,54 @@ class DeviceProver:
             return t
 
         self.seeds = dict(a=101, b1=102, b2=103, h=104, l=105, fixed1=106, fixed2=107)
-        # index 0 of the a/b generators is query[0]; MSM index i is generator index 1 + i
-        bufs = dict(
-            a=synth(False, self.seeds["a"], 1 + a_lo, a_hi - a_lo), b1=synth(False, self.seeds["b1"], 1 + a_lo, a_hi - a_lo),
-            b2=synth(True, self.seeds["b2"], 1 + a_lo, a_hi - a_lo), h=synth(False, self.seeds["h"], h_lo, h_hi - h_lo),
-            l=synth(False, self.seeds["l"], l_lo, l_hi - l_lo))
-        q0a = synth(False, self.seeds["a"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
-        q0b1 = synth(False, self.seeds["b1"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
-        q0b2 = synth(True, self.seeds["b2"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
-        f1 = synth(False, self.seeds["fixed1"], 0, 3).cpu().numpy().view(np.uint64)  # alpha_g1, beta_g1, delta_g1
-        f2 = synth(True, self.seeds["fixed2"], 0, 2).cpu().numpy().view(np.uint64)   # beta_g2, delta_g2
-        self.fixed = dict(alpha_g1=f1[0].copy(), beta_g1=f1[1].copy(), delta_g1=f1[2].copy(), beta_g2=f2[0].copy(),
-                          delta_g2=f2[1].copy(), a0=q0a.copy(), b10=q0b1.copy(), b20=q0b2.copy())
+        if key == "valid":
+            # Groth16::generate_parameters_with_qap (generator.rs:47-208) straight into HBM; every rank derives the same key
+            # from the same seed and keeps its shard
+            rs = np.random.RandomState(20240 + seed)
+            mod = _MODULUS_R[curve]
+
+            def rand_fr():
+                v = int.from_bytes(rs.bytes(64), "little") % mod or 1
+                v = (v << 256) % mod   # Montgomery form
+                return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+            tw = ToxicWasteC()
+            for name in ("alpha", "beta", "gamma", "delta", "t"):
+                getattr(tw, name)[:] = rand_fr()
+            gen1 = synth(False, self.seeds["fixed1"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1).copy()
+            gen2 = synth(True, self.seeds["fixed2"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1).copy()
+            full = dict(a=torch.empty((self.nvars, 2 * L), dtype=torch.int64, device=dev),
+                        b1=torch.empty((self.nvars, 2 * L), dtype=torch.int64, device=dev),
+                        b2=torch.empty((self.nvars, 4 * L), dtype=torch.int64, device=dev),
+                        h=torch.empty((hlen, 2 * L), dtype=torch.int64, device=dev), l=torch.empty((w, 2 * L), dtype=torch.int64, device=dev))
+            fx = dict(alpha_g1=np.zeros(2 * L, dtype=np.uint64), beta_g1=np.zeros(2 * L, dtype=np.uint64), delta_g1=np.zeros(2 * L, dtype=np.uint64),
+                      beta_g2=np.zeros(4 * L, dtype=np.uint64), delta_g2=np.zeros(4 * L, dtype=np.uint64))
+            self.vk_rest = dict(gamma_g2=np.zeros(4 * L, dtype=np.uint64), gamma_abc_g1=np.zeros((self.nin, 2 * L), dtype=np.uint64))
+            out = ParamsViewC(ptr64(fx["alpha_g1"]), ptr64(fx["beta_g1"]), ptr64(fx["delta_g1"]), ptr64(fx["beta_g2"]), ptr64(fx["delta_g2"]),
+                              ptr64(self.vk_rest["gamma_g2"]), ptr64(self.vk_rest["gamma_abc_g1"]), C.c_void_p(full["a"].data_ptr()),
+                              C.c_void_p(full["b1"].data_ptr()), C.c_void_p(full["b2"].data_ptr()), C.c_void_p(full["h"].data_ptr()),
+                              C.c_void_p(full["l"].data_ptr()), 1)
+            self.lib.check(c.g16_generate_parameters(self.ctx, views, self.nin, nc, self.nvars, C.byref(tw), ptr64(gen1), ptr64(gen2),
+                                                     C.byref(out)))
+            bufs = dict(a=full["a"][1 + a_lo: 1 + a_hi], b1=full["b1"][1 + a_lo: 1 + a_hi], b2=full["b2"][1 + a_lo: 1 + a_hi],
+                        h=full["h"][h_lo: h_hi], l=full["l"][l_lo: l_hi])
+            u64 = lambda t: t.cpu().numpy().view(np.uint64).reshape(-1).copy()  # noqa: E731
+            fx.update(a0=u64(full["a"][0]), b10=u64(full["b1"][0]), b20=u64(full["b2"][0]))
+            self.fixed = fx
+            self._full = full   # the slices above are views of these
+        else:
+            # index 0 of the a/b generators is query[0]; MSM index i is generator index 1 + i
+            bufs = dict(
+                a=synth(False, self.seeds["a"], 1 + a_lo, a_hi - a_lo), b1=synth(False, self.seeds["b1"], 1 + a_lo, a_hi - a_lo),
+                b2=synth(True, self.seeds["b2"], 1 + a_lo, a_hi - a_lo), h=synth(False, self.seeds["h"], h_lo, h_hi - h_lo),
+                l=synth(False, self.seeds["l"], l_lo, l_hi - l_lo))
+            q0a = synth(False, self.seeds["a"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
+            q0b1 = synth(False, self.seeds["b1"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
+            q0b2 = synth(True, self.seeds["b2"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
+            f1 = synth(False, self.seeds["fixed1"], 0, 3).cpu().numpy().view(np.uint64)  # alpha_g1, beta_g1, delta_g1
+            f2 = synth(True, self.seeds["fixed2"], 0, 2).cpu().numpy().view(np.uint64)   # beta_g2, delta_g2
+            self.fixed = dict(alpha_g1=f1[0].copy(), beta_g1=f1[1].copy(), delta_g1=f1[2].copy(), beta_g2=f2[0].copy(),
+                              delta_g2=f2[1].copy(), a0=q0a.copy(), b10=q0b1.copy(), b20=q0b2.copy())
 
         def q(t, lo, hi):
             return QueryC(t.data_ptr() if hi > lo else None, hi - lo, lo)
@@ -154,7 +194,7 @@ def default_cpu_threads():
     return ncpu
 
 
-def cpu_baseline(curve, k_cpu, seed, threads):
+def cpu_baseline(curve, k_cpu, seed, threads, key="valid"):
     """CPU oracle on a bounded sample: same circuit family / key shape at k_cpu; pk generated on the GPU and
     downloaded so that GPU and CPU prove the very same instance (also a parity check of this bench)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -162,7 +202,7 @@ def cpu_baseline(curve, k_cpu, seed, threads):
 
     orc = oracle()
     orc.set_threads(threads or default_cpu_threads())
-    dp = DeviceProver(curve, k_cpu, seed, 0, 1, torch.cuda.current_device())
+    dp = DeviceProver(curve, k_cpu, seed, 0, 1, torch.cuda.current_device(), key)
     gpu_proof = dp.finalize([dp.partial()])
     rp, cols, val = dp.csr_host
     ck = FlatCircuit(curve, dp.nin, dp.nc, dp.nvars, [Csr(rp, cols[i], val) for i in range(3)], dp.z_host)
@@ -195,6 +235,8 @@ def main():
     ap.add_argument("--cpu-log2", type=int, default=int(os.environ.get("G16_BENCH_CPU_LOG2", "18")))
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("G16_BENCH_CPU_THREADS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--key", choices=["valid", "synthetic"], default=os.environ.get("G16_BENCH_KEY", "valid"),
+                    help="valid: CRS of the circuit generated on the GPU (g16_generate_parameters); synthetic: arbitrary distinct points")
     ap.add_argument("--sim-shards", type=int, default=0,
                     help="DIAGNOSTIC, not a benchmark: time one rank's share of an N-way sharded proof on a single GPU "
                          "(shard 0 of N, no exchange); the JSON line is tagged and must not be read as throughput")
@@ -233,7 +275,7 @@ def main():
 
     if args.sim_shards:
         assert world == 1
-        p = DeviceProver(args.curve, args.log2, 1, 0, args.sim_shards, local_rank)
+        p = DeviceProver(args.curve, args.log2, 1, 0, args.sim_shards, local_rank, args.key)
         for _ in range(args.warmup):
             p.partial()
         torch.cuda.synchronize()
@@ -248,7 +290,10 @@ def main():
         print(json.dumps({"diagnostic": "per-rank share of a sharded proof (NOT a throughput number)", "sim_shards": args.sim_shards,
                           "log2": args.log2, "partial_ms": 1e3 * dt, "finalize_ms": 1e3 * fin, "phases": p.timings()}), flush=True)
         return
-    p = DeviceProver(args.curve, args.log2, 1, rank, world, local_rank)
+    t_setup = time.perf_counter()
+    p = DeviceProver(args.curve, args.log2, 1, rank, world, local_rank, args.key)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
     proof = None
     for _ in range(args.warmup):
         proof = prove_step(p, dist, device)
@@ -316,8 +361,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32-limb Montgomery integers (Fr 255-bit, Fq 381-bit)", "data": "synthetic",
             "config": {"workload": f"SYN(k={args.log2}) synthetic R1CS, {p.nc} constraints, FFT domain 2^{args.log2}, {args.curve}, "
-                                   f"full create_proof (7 NTTs + 4 G1 MSMs + 1 G2 MSM), synthetic-bases proving key",
-                       "curve": args.curve, "log2_domain": args.log2, "constraints": p.nc,
+                                   f"full create_proof (7 NTTs + 4 G1 MSMs + 1 G2 MSM), "
+                                   + ("valid proving key generated on the GPU from seeded toxic waste" if args.key == "valid"
+                                      else "synthetic-bases proving key"),
+                       "curve": args.curve, "log2_domain": args.log2, "constraints": p.nc, "key": args.key,
+                       "untimed_setup_s": round(t_setup, 2),
                        "parallelism": f"msm-base-shard x{world}" if world > 1 else "single-gpu"},
             "roofline": roofline,
             "phases_ms_per_step": {k_: round(v / args.steps, 3) for k_, v in phase_acc.items()},
@@ -328,7 +376,7 @@ def main():
             out["proof_sha256"] = hashlib.sha256(proof.tobytes()).hexdigest()
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.curve, args.cpu_log2, 1, args.cpu_threads)
+                out["cpu_baseline"] = cpu_baseline(args.curve, args.cpu_log2, 1, args.cpu_threads, args.key)
             except Exception as e:  # noqa: BLE001 -- the baseline leg must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

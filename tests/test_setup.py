@@ -115,10 +115,12 @@ def test_generate_parameters_matches_oracle(orc, cp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cp,k", [(pm.BLS12_381, 18), (pm.BN254, 16)], ids=["bls12_381-2^18", "bn254-2^16"])
+@pytest.mark.parametrize("cp,k", [(pm.BLS12_381, 18), (pm.BN254, 16), (pm.BLS12_381, 22)], ids=["bls12_381-k18", "bn254-k16", "bls12_381-k22"])
 def test_setup_prove_verify_on_gpu(orc, cp, k):
-    """the reference's end-to-end pattern at a size the CPU setup would need minutes for: key from g16_generate_parameters,
-    proof from g16_prove with fresh r, s, accepted by the pairing verifier, rejected on a wrong public input"""
+    """the reference's end-to-end pattern at sizes the CPU setup would need minutes for, up to BASELINE.json's full size
+    (2^22 constraints: the merged-window MSM with 16 bucket classes, every kernel at its benchmark shape): key from
+    g16_generate_parameters, proof from g16_prove with fresh r, s, accepted by the pairing verifier, rejected on a wrong
+    public input"""
     import groth16_amd as g
     from test_verifier import _proof_from_flat
     from helpers import arr_to_g1, arr_to_g2
