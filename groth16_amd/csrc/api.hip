@@ -140,6 +140,9 @@ struct Impl {
         for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
         const int W = msm_plan_windows(c, Fr::Params::BITS, modw, Fr::N);
         if (W <= 0) return G16_ERR_INTERNAL;
+        // G16_PK_TABLE_BUDGET_MB caps one query's table (default: whatever hipMalloc grants); past it the key is held plain
+        const char* cap = getenv("G16_PK_TABLE_BUDGET_MB");
+        if (cap && (double)q.count * sizeof(P) * W > atof(cap) * 1048576.0) return G16_ERR_OOM;
         if (hipMalloc((void**)out, q.count * sizeof(P) * (size_t)W) != hipSuccess) return G16_ERR_OOM;
         const P* src = reinterpret_cast<const P*>(q.points);
         P* staged = nullptr;

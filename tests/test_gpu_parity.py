@@ -194,11 +194,13 @@ def test_proof_valid_crs_2_16_trapdoor_and_pairing(env, orc, g):
 
 
 @pytest.mark.parametrize("scheme", [{"G16_MSM_PRECOMP": "0"}, {"G16_MSM_PRECOMP_WINDOW": "16"}, {"G16_MSM_PRECOMP_WINDOW": "17"},
-                                    {"G16_MSM_PRECOMP_WINDOW": "20"}], ids=["plain_bases", "tables_c16", "tables_c17", "tables_c20"])
+                                    {"G16_MSM_PRECOMP_WINDOW": "20"}, {"G16_PK_TABLE_BUDGET_MB": "2.0"}],
+                         ids=["plain_bases", "tables_c16", "tables_c17", "tables_c20", "tables_do_not_fit"])
 def test_proof_bucket_schemes(env, orc, g, scheme, monkeypatch):
     """g16_pk_load decides how the key is held (plain bases + per-window buckets, or window tables + merged windows at
     the window size of the cost model); every choice must give the oracle's proof, including the 16-class shape of a
-    2^22 key and a sharded key whose l range needs its own sort"""
+    2^22 key, a sharded key whose l range needs its own sort, and the fall-back to plain bases when a table cannot be
+    allocated (here: a 2 MB cap that the G2 table of this 512-constraint key exceeds after the G1 tables were built)"""
     curve, prover = env
     for k_, v in scheme.items():
         monkeypatch.setenv(k_, v)
