@@ -85,6 +85,8 @@ template <class C> int domain_ensure_gpow(Domain<C>* d, hipStream_t st);
 template <class C> int ntt_dif(const Domain<C>* d, typename C::Fr* data, bool inverse, hipStream_t st);
 // bit-reversed -> natural (Cooley-Tukey); each input element is first multiplied by prescale[i] if non-null
 template <class C> int ntt_dit(const Domain<C>* d, typename C::Fr* data, bool inverse, const typename C::Fr* prescale, hipStream_t st);
+// ntt_dif(inverse = dif_inverse) then ntt_dit(inverse = !dif_inverse, prescale); the two innermost passes share one kernel
+template <class C> int ntt_dif_dit(const Domain<C>* d, typename C::Fr* data, bool dif_inverse, const typename C::Fr* prescale, hipStream_t st);
 // out[k] = in[bitrev(k)] * table[k] * cst  (table may be null; has_cst selects the constant factor)
 template <class C> int bitrev_scale(const Domain<C>* d, typename C::Fr* out, const typename C::Fr* in, const typename C::Fr* table,
                                     const typename C::Fr* cst, hipStream_t st);

@@ -167,6 +167,64 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(Fp<P>* __restri
     }
 }
 
+// The last pass of a DIF transform and the first pass of the DIT transform that follows it work on the same contiguous
+// tiles (stages [0, K)): fused, the tile stays in LDS in between -- one HBM round trip, one canonicalisation and one launch
+// less per DIF/DIT pair (three pairs per witness map).  `prescale` is applied between the two (x lazy, < 2^K p: fine for
+// the product).
+template <class P>
+__global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(Fp<P>* __restrict__ data, const Fp<P>* __restrict__ tw_dif,
+                                                                    const Fp<P>* __restrict__ tw_dit, const Fp<P>* __restrict__ prescale,
+                                                                    int log_n, int K) {
+    typedef Fp30<P> F;
+    constexpr int NL = F::NL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lds = reinterpret_cast<uint32_t*>(smem);  // [NL][NTT_ROW]
+    const uint32_t E = 1u << K;
+    const uint64_t base = (uint64_t)blockIdx.x << K;
+    auto gidx = [&](uint32_t e) -> uint64_t { return base + e; };
+    for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
+        const F x = F::unpack(data[base + e].v);
+        const uint32_t c = lds_col(e);
+        G16_UNROLL for (int l = 0; l < NL; ++l) lds[l * NTT_ROW + c] = x.l[l];
+    }
+    __syncthreads();
+    for (int done = 0; done < K;) {
+        const int R = (K - done) >= 3 ? 3 : (K - done);
+        const int q0 = K - done - R;
+        if (R == 3) ntt30_round<P, false, 3>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx);
+        else if (R == 2) ntt30_round<P, false, 2>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx);
+        else ntt30_round<P, false, 1>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx);
+        __syncthreads();
+        done += R;
+    }
+    if (prescale) {   // each lane rewrites the columns it reads: no barrier inside the loop
+        for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
+            const uint32_t c = lds_col(e);
+            F x;
+            G16_UNROLL for (int l = 0; l < NL; ++l) x.l[l] = lds[l * NTT_ROW + c];
+            x = x.mul_impl(F::unpack(prescale[base + e].v));
+            G16_UNROLL for (int l = 0; l < NL; ++l) lds[l * NTT_ROW + c] = x.l[l];
+        }
+        __syncthreads();
+    }
+    for (int done = 0; done < K;) {
+        const int R = (K - done) >= 3 ? 3 : (K - done);
+        if (R == 3) ntt30_round<P, true, 3>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx);
+        else if (R == 2) ntt30_round<P, true, 2>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx);
+        else ntt30_round<P, true, 1>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx);
+        __syncthreads();
+        done += R;
+    }
+    for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
+        const uint32_t c = lds_col(e);
+        F x;
+        G16_UNROLL for (int l = 0; l < NL; ++l) x.l[l] = lds[l * NTT_ROW + c];
+        Fp<P> o;
+        x.mul_impl(F::one()).canonical_lt2p().pack(o.v);
+        data[base + e] = o;
+    }
+}
+
 // out[k] = in[bitrev(k)] * table[k] * cst      (table / cst in the w*R' form; either may be absent)
 template <class P>
 __global__ void bitrev_scale_kernel(Fp<P>* __restrict__ out, const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ table, Fp<P> cst,
@@ -261,6 +319,36 @@ int ntt_dit(const Domain<C>* d, typename C::Fr* data, bool inverse, const typena
     return G16_OK;
 }
 
+// ntt_dif(inverse = dif_inverse) followed by ntt_dit(inverse = !dif_inverse, prescale), with the two innermost passes fused
+template <class C>
+int ntt_dif_dit(const Domain<C>* d, typename C::Fr* data, bool dif_inverse, const typename C::Fr* prescale, hipStream_t st) {
+    typedef typename C::Fr::Params P;
+    if (d->log_n == 0) {
+        if (prescale) G16_TRY((scale_by_table<C>(data, prescale, 1, st)));
+        return G16_OK;
+    }
+    auto passes = plan_passes(d->log_n);
+    const typename C::Fr* tw1 = dif_inverse ? d->tw_inv : d->tw_fwd;
+    const typename C::Fr* tw2 = dif_inverse ? d->tw_fwd : d->tw_inv;
+    for (size_t i = passes.size(); i-- > 1;) G16_TRY((launch_pass<P, false>(data, tw1, nullptr, d->log_n, passes[i], st)));
+    {
+        const int K = passes[0].s_hi;
+        const size_t blocks = ((size_t)1 << d->log_n) >> K;
+        const size_t lds_bytes = (size_t)Fp30<P>::NL * NTT_ROW * sizeof(uint32_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt30_dif_dit_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_bytes));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((ntt30_dif_dit_kernel<P>), dim3((unsigned)blocks), dim3(NTT_THREADS), lds_bytes, st, data, tw1, tw2, prescale,
+                           d->log_n, K);
+        G16_LAUNCH_CHECK();
+    }
+    for (size_t i = 1; i < passes.size(); ++i) G16_TRY((launch_pass<P, true>(data, tw2, nullptr, d->log_n, passes[i], st)));
+    return G16_OK;
+}
+
 template <class C>
 int bitrev_scale(const Domain<C>* d, typename C::Fr* out, const typename C::Fr* in, const typename C::Fr* table,
                  const typename C::Fr* cst, hipStream_t st) {
@@ -345,6 +433,7 @@ void domain_destroy(Domain<C>* d) {
     template int domain_ensure_gpow<C>(Domain<C>*, hipStream_t);                                                   \
     template int ntt_dif<C>(const Domain<C>*, typename C::Fr*, bool, hipStream_t);                                 \
     template int ntt_dit<C>(const Domain<C>*, typename C::Fr*, bool, const typename C::Fr*, hipStream_t);          \
+    template int ntt_dif_dit<C>(const Domain<C>*, typename C::Fr*, bool, const typename C::Fr*, hipStream_t);      \
     template int bitrev_scale<C>(const Domain<C>*, typename C::Fr*, const typename C::Fr*, const typename C::Fr*,  \
                                  const typename C::Fr*, hipStream_t);                                              \
     template int scale_by_table<C>(typename C::Fr*, const typename C::Fr*, size_t, hipStream_t);

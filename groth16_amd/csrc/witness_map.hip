@@ -72,8 +72,8 @@ int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, ty
                        ck->num_constraints, (uint64_t)n);
     G16_LAUNCH_CHECK();
     for (int m = 0; m < 3; ++m) {
-        G16_TRY((ntt_dif<C>(dom, outs[m], /*inverse=*/true, st)));
-        G16_TRY((ntt_dit<C>(dom, outs[m], /*inverse=*/false, dom->s1_br, st)));
+        // ifft then coset fft (r1cs_to_qap.rs:201-207): inverse DIF, n^-1 g^bitrev(i), forward DIT
+        G16_TRY((ntt_dif_dit<C>(dom, outs[m], /*dif_inverse=*/true, dom->s1_br, st)));
     }
     hipLaunchKernelGGL((quotient_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, c, dom->zinv, n);
     G16_LAUNCH_CHECK();
