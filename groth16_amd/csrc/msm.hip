@@ -16,7 +16,7 @@
 //                           slice and LDS atomics hand out the slots: a counting sort of
 //                           (point index | sign) by (window, bucket) -- order inside a bucket is
 //                           irrelevant because group addition commutes
-//   5. bucket_accumulate30_kernel  THE hot kernel: one lane (G1) / lane pair (G2) per 128-entry SEGMENT of the
+//   5. bucket_accumulate30_kernel  THE hot kernel: one lane (G1) / lane pair (G2) per 64-entry SEGMENT of the
 //                           sorted list gathers affine bases (96 B / 192 B each) and folds them with XYZZ
 //                           mixed additions (8M+2S, no inversion) in 30-bit lazy arithmetic (fp30.hpp),
 //                           flushing one partial sum per (bucket, segment) it touches
@@ -636,14 +636,20 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
         plan->groups = W;
     }
     const uint64_t entries = n * (uint64_t)W;
-    // segment length of the bucket pass: 128 entries per lane, shorter for small inputs so that the pass still has
-    // >= ~4 segments per lane slot of the chip (256 CUs x 4 SIMDs x 2 waves x 64 lanes)
-    uint32_t l = 128;
+    // segment length of the bucket pass: 64 entries per lane (a pass ends with one partly filled round of segments, ~1/2
+    // segment time on average: 64 measured 1 % faster than 128 at 2^22, 256 is 13 % slower, 32 drowns in partial sums),
+    // shorter for small inputs so that the pass still has >= ~4 segments per lane slot of the chip
+    // (256 CUs x 4 SIMDs x 2 waves x 64 lanes)
+    uint32_t l = 64;
     while (l > 16 && entries / l < 4ull * 131072ull) l >>= 1;
     // ... but never much shorter than the mean bucket load: a bucket of ~mean entries then touches at most ~5 segments and
     // stays below the heavy-bucket threshold (otherwise EVERY bucket would go through the cooperative combine)
     const uint64_t mean = entries / plan->buckets() + 1;
     while (l < 128 && (uint64_t)l * 4 < mean) l <<= 1;
+    if (const char* e = getenv("G16_MSM_SEGMENT")) {   // experiments: force the segment length (power of two, 16..1024)
+        const int v = atoi(e);
+        if (v >= 16 && v <= 1024 && (v & (v - 1)) == 0) l = (uint32_t)v;
+    }
     plan->Lmax = l;
     // histogram / scatter chunking: ~2048 workgroups in total, chunk a multiple of 1024 points
     uint64_t nchunks = 2048 / (uint64_t)plan->groups;
