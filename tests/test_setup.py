@@ -137,3 +137,34 @@ def test_setup_prove_verify_on_gpu(orc, cp, k):
     public = mont_to_ints(ck.z[1: ck.num_inputs], cp.r)
     assert pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), public)
     assert not pm.verify_proof(cp, vk, _proof_from_flat(cp, proof.flat()), [(public[0] + 1) % cp.r])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
+def test_generate_parameters_reproduces_golden_keys(cp):
+    """the proving keys frozen in tests/golden/*.json (big-int model, checked there against the trapdoor closed form) come
+    back array for array from g16_generate_parameters when it is given the model's toxic waste and generators"""
+    import groth16_amd as g
+    from helpers import g1_to_arr, g2_to_arr
+    from test_golden import load_cases
+
+    seeds = {"syn3": 7, "syn5_dense": 8, "mimc7": 9}      # tests/golden/make_golden.py
+    fr = lambda v: ints_to_mont([v], cp.r, 4)[0]          # noqa: E731
+    seen = set()
+    with g.Groth16(cp.name, 0) as prover:
+        for name, _, cs, z, _r, _s, pk, _ex in load_cases(cp.name):
+            base = name.rsplit("_", 1)[0]
+            if base in seen:
+                continue
+            seen.add(base)
+            _, td = pm.generate_parameters(cp, cs, seeds[base])
+            ck = circuit_from_pymodel(cp, cs, z)
+            got = prover.generate_parameters_with_qap(_mats(g, ck), fr(td.alpha), fr(td.beta), fr(td.gamma), fr(td.delta),
+                                                      g1_to_arr([td.g1], cp)[0], g2_to_arr([td.g2], cp)[0], fr(td.t))
+            for field, conv in (("alpha_g1", g1_to_arr), ("beta_g1", g1_to_arr), ("delta_g1", g1_to_arr), ("beta_g2", g2_to_arr),
+                                ("delta_g2", g2_to_arr)):
+                assert (getattr(got, field).reshape(-1) == conv([getattr(pk, field)], cp)[0]).all(), (name, field)
+            for field, conv in (("a_query", g1_to_arr), ("b_g1_query", g1_to_arr), ("b_g2_query", g2_to_arr), ("h_query", g1_to_arr),
+                                ("l_query", g1_to_arr)):
+                assert (getattr(got, field) == conv(getattr(pk, field), cp)).all(), (name, field)
+    assert seen == set(seeds)
