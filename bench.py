@@ -255,10 +255,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     dist = None
-    if world > 1:
+    # G16_BENCH_FORCE_DIST (test-only): take the collective path with a single rank too, so that the RCCL calls the N > 1 runs
+    # make (process group on a device, all-gather / all-reduce / barrier on device tensors) can be exercised on a 1-GPU box
+    if world > 1 or os.environ.get("G16_BENCH_FORCE_DIST"):
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:

@@ -30,6 +30,16 @@ void set_last_error(const char* what, hipError_t e, const char* file, int line);
 
 #define G16_LAUNCH_CHECK() G16_HIP_TRY(hipGetLastError())
 
+// hipFuncSetAttribute is per device: one "already raised the dynamic-LDS limit" flag per (call site, device)
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool& flag() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return done[dev & 63];
+    }
+};
+
 // Device scratch arena: chunks are retained across calls (first call pays hipMalloc), offsets
 // reset at the start of each top-level call.  Sized for 288 GB of HBM: nothing is ever freed
 // mid-proof, so there is no hipFree-induced device sync on the hot path.

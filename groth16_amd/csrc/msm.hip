@@ -704,7 +704,8 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     pd.c = plan.c; pd.W = plan.W; pd.B = plan.B;
     for (int k = 0; k < 10; ++k) pd.K[k] = plan.K[k];
     const size_t lds = (size_t)plan.B * sizeof(uint32_t);
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
+    bool& attr_set = attr_once.flag();
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         128 * 1024));
@@ -800,7 +801,8 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     const MsmPlan& plan = ss.plan;
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
+    bool& attr_set = attr_once.flag();
     const size_t lds_heavy = sizeof(Raw) * HEAVY_THREADS, lds_win = sizeof(Raw) * WIN_THREADS;
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&heavy_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -291,3 +291,26 @@ def test_bench_two_ranks_one_gpu():
     d1 = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and d2["scaling"] == "strong"
     assert d2["proof_sha256"] == d1["proof_sha256"]
+
+
+def test_bench_rccl_single_rank():
+    """the collective path of bench.py over RCCL itself (backend "nccl"): one rank on the one visible GPU -- process group
+    bound to the device, all-gather of the partial records as device tensors, all-reduce of the timing, barrier.  Proof
+    must equal the plain single-GPU run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 31000 + os.getpid() % 2000
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log2", "12", "--no-cpu-baseline"]
+    env = dict(os.environ, G16_BENCH_PRINT_PROOF="1")
+    envd = dict(env, G16_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    outd = subprocess.run(base, env=envd, capture_output=True, text=True, timeout=600)
+    assert outd.returncode == 0, outd.stderr[-3000:]
+    out1 = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600)
+    assert out1.returncode == 0, out1.stderr[-3000:]
+    dd = json.loads([l for l in outd.stdout.splitlines() if l.startswith("{")][-1])
+    d1 = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
+    assert dd["proof_sha256"] == d1["proof_sha256"] and dd["n_gpus"] == 1
