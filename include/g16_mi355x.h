@@ -62,7 +62,13 @@ typedef struct {
     uint64_t start;         /* index of points[0] within the logical MSM base array               */
 } g16_query;
 
-#define G16_PK_DEVICE_PTRS 1u /* query `points` are device pointers on the ctx's GPU (copied D2D) */
+#define G16_PK_DEVICE_PTRS 1u /* query `points` are device pointers on the ctx's GPU */
+
+/* g16_pk_load never modifies or retains the caller's arrays.  What it keeps on the GPU per query is either the
+ * bases (in the bucket kernel's radix) or -- the default -- their WINDOW TABLE: W rows 2^(c j) * query, c = 20 and
+ * W = 13 for keys of 2^20 points and more, i.e. 13x the memory of the key (31 GB for 2^22 BLS12-381 constraints),
+ * which cuts the prover's dominant kernel by a fifth.  Environment: G16_MSM_PRECOMP=0 keeps plain
+ * bases; G16_PK_TABLE_BUDGET_MB caps one query's table; a failed allocation falls back to plain bases. */
 
 /* ProvingKey<E> as the prover reads it (src/data_structures.rs:125-143; vk fields prover.rs:92,105,113).
  * MSM base arrays, in the index space the prover uses:
