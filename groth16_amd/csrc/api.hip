@@ -417,7 +417,7 @@ struct Impl {
 
         g16_timings& tm = ctx->tm;
         memset(&tm, 0, sizeof(tm));
-        auto span = [&](int k) -> double {  // bucket pass start (stream 1) -> window sums on the host (stream 2)
+        auto span = [&](int k) -> double {  // bucket pass start (stream 1) -> group sums on the host (reduction stream)
             float t = 0.f;
             return hipEventElapsedTime(&t, ctx->ev_msm_start[k], ctx->ev_done[k]) == hipSuccess ? (double)t : 0.0;
         };
@@ -774,8 +774,9 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
     c->curve = curve;
     c->device = device_id;
     memset(&c->tm, 0, sizeof(c->tm));
-    // stream 2 carries the short, latency-bound work on the critical path of the h MSM (witness map, digit/sort, reductions):
-    // give it priority over the long bucket passes it runs underneath
+    // streams 2, 3 and the reduction streams carry the short, latency-bound work (digit/sort passes, reductions): give them
+    // priority over the long bucket passes they run underneath (measured effect: small -- a kernel whose waves hold every
+    // register slot for milliseconds is not displaced by priority; see prove_partial)
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lower = higher priority
     bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&

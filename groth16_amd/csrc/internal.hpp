@@ -161,7 +161,7 @@ template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n,
 //                    0 <= p + shift < base_count (other entries are skipped: lets l_query reuse the sort made for a/b);
 //                    with a merged plan `d_bases` is the window table and entry (j, p) addresses [j * base_count + p + shift]
 //   msm_reduce       heavy-bucket combine, bucket reduction, window reduction (latency-bound, few waves): meant to
-//                    run on a second stream underneath the next MSM's bucket pass.  Leaves plan.outputs() sums (standard
+//                    run on another stream underneath the next MSM's bucket pass.  Leaves plan.outputs() sums (standard
 //                    Montgomery form, XYZZ) in buf.window_sums: per group sum_b (b+1) S_b, then (merged) per group sum_b S_b.
 template <class F>
 struct MsmBuffers {
