@@ -343,14 +343,14 @@ struct Impl {
         MsmBuffers<Fq> buf_h, buf_l, buf_a, buf_b1;
         MsmBuffers<Fq2> buf_b2;
         // window sums of MSM k land in the pinned host buffer; slot layout by MSM order (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2)
-        const size_t SLOT = 96 * sizeof(G2X);  // W <= 86 for every admissible window size
+        const size_t SLOT = MSM_MAX_OUTPUTS * sizeof(G2X);  // plan.outputs() <= 224 for every admissible plan
         if (ctx->pinned_bytes < 5 * SLOT) {
             if (ctx->pinned) (void)hipHostFree(ctx->pinned);
             G16_HIP_TRY(hipHostMalloc(&ctx->pinned, 5 * SLOT, hipHostMallocDefault));
             ctx->pinned_bytes = 5 * SLOT;
         }
         char* pin = static_cast<char*>(ctx->pinned);
-        if (sort_z.plan.outputs() > 96 || sort_h.plan.outputs() > 96) return G16_ERR_INTERNAL;
+        if (sort_z.plan.outputs() > MSM_MAX_OUTPUTS || sort_h.plan.outputs() > MSM_MAX_OUTPUTS) return G16_ERR_INTERNAL;
         // bucket pass on stream 1; reduction + copy-out underneath the following passes.  A reduction is a chain of
         // dependent additions in a few waves (G1 ~1.5 ms, G2 ~9 ms, independent of the shard size).  Long passes (whole
         // key): all reductions queue on stream 2 -- side by side they take more from the passes than they give back
@@ -716,7 +716,8 @@ struct Impl {
                 buckets[plan.merged ? (size_t)bucket : (size_t)w * plan.B + bucket].add_affine(q);
             }
         }
-        const uint32_t G = plan.B >= 8 ? 8u : plan.B, cpw = plan.B / G;
+        const uint32_t G = plan.chunk_buckets(), cpw = plan.chunks();
+        const int NP = plan.planes();
         std::vector<X> wsum(plan.outputs(), X::identity());
         for (int w = 0; w < plan.groups; ++w) {
             for (uint32_t ch = 0; ch < cpw; ++ch) {
@@ -726,15 +727,10 @@ struct Impl {
                     run.add(buckets[(size_t)w * plan.B + b_lo + bb]);
                     tot.add(run);
                 }
-                if (plan.outputs() > plan.groups) wsum[plan.groups + w].add(run);
-                if (b_lo) {
-                    uint32_t kk[1] = {b_lo};
-                    int nb = 0;
-                    while ((b_lo >> nb) != 0) ++nb;
-                    X mm = run.mul_bits(kk, nb);
-                    tot.add(mm);
-                }
-                wsum[w].add(tot);
+                wsum[(size_t)w * NP + 0].add(tot);                                   // plane 0: weighted chunk sums
+                wsum[(size_t)w * NP + 1].add(run);                                   // plane 1: plain chunk sums
+                for (int k = 0; k < plan.chunk_bits(); ++k)
+                    if ((ch >> k) & 1) wsum[(size_t)w * NP + 2 + k].add(run);        // plane 2 + k: chunks with bit k set
             }
         }
         const A res = fold_windows<F>(wsum.data(), plan).to_affine();

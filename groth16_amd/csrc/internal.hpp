@@ -132,8 +132,17 @@ struct MsmPlan {
     uint32_t chunk = 0; // points per histogram/scatter block
     uint32_t K[10];     // signed-digit bias  sum_w 2^(c-1) 2^(cw)
     uint32_t buckets() const { return B * (uint32_t)groups; }
-    int outputs() const { return merged && groups > 1 ? 2 * groups : groups; }  // XYZZ sums leaving the device per MSM
+    // Reduction of one group of B buckets: chunks of G = min(8, B) buckets per lane give (sum_b (b - b_lo + 1) S_b, sum_b S_b);
+    // the chunk offsets b_lo = G * ch are applied WITHOUT a scalar multiplication in the dependent chain: the window level
+    // sums the chunk sums once per bit of ch (masked tree sums, all in parallel) and the host recombines
+    //   sum_b (b + 1) S_b = P_0 + G * sum_k 2^k P_(2+k),   sum_b S_b = P_1.
+    uint32_t chunk_buckets() const { return B >= 8 ? 8u : B; }
+    uint32_t chunks() const { return B / chunk_buckets(); }
+    int chunk_bits() const { int k = 0; while ((1u << k) < chunks()) ++k; return k; }
+    int planes() const { return 2 + chunk_bits(); }                // sums per group leaving the device
+    int outputs() const { return groups * planes(); }             // XYZZ sums leaving the device per MSM (<= 224)
 };
+static constexpr int MSM_MAX_OUTPUTS = 256;
 static constexpr int MSM_MERGED_MIN_C = 9, MSM_MERGED_MAX_C = 20;   // merged entries pack window j < 32 and point i < 2^26
 static constexpr uint64_t MSM_MERGED_MAX_N = (uint64_t)1 << 26;
 // merged_c = 0: per-window plan, window size from the cost model (or G16_MSM_WINDOW); else a merged plan with that c
@@ -162,7 +171,7 @@ template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n,
 //                    with a merged plan `d_bases` is the window table and entry (j, p) addresses [j * base_count + p + shift]
 //   msm_reduce       heavy-bucket combine, bucket reduction, window reduction (latency-bound, few waves): meant to
 //                    run on another stream underneath the next MSM's bucket pass.  Leaves plan.outputs() sums (standard
-//                    Montgomery form, XYZZ) in buf.window_sums: per group sum_b (b+1) S_b, then (merged) per group sum_b S_b.
+//                    Montgomery form, XYZZ) in buf.window_sums: plan.planes() sums per group (see MsmPlan).
 template <class F>
 struct MsmBuffers {
     void* partials = nullptr;    // AccRaw records (lazy limbs), one per (bucket, segment) pair
@@ -175,7 +184,7 @@ template <class F> int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss
 // MSM bases are kept on the device in the bucket kernel's own Montgomery radix (x*R' with R' = 2^(30 NL), canonical,
 // packed in the usual words): converted in place, once, after upload (F = Fq for G1, Fq2 for G2).
 template <class F> int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st);
-// host: sum_w 2^(c w) R_w (per-window plan) or sum_q T_q + B sum_q q S_q (merged plan)
+// host: per group T = P_0 + G sum_k 2^k P_(2+k), S = P_1; then sum_w 2^(c w) T_w (per-window plan) or sum_q T_q + B sum_q q S_q (merged)
 template <class F> XYZZ<F> fold_windows(const XYZZ<F>* window_sums, const MsmPlan& plan);
 // window tables for a merged plan: table[j * n + i] = 2^(c j) * src[i] for j < W, affine, in the bucket kernel's radix
 // (what convert_bases leaves); src holds standard-form affine points and is not modified

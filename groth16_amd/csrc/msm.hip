@@ -21,8 +21,9 @@
 //                           mixed additions (8M+2S, no inversion) in 30-bit lazy arithmetic (fp30.hpp),
 //                           flushing one partial sum per (bucket, segment) it touches
 //   5b. heavy_reduce_kernel cooperative combine of buckets with many partial sums
-//   6. bucket_reduce_kernel / window_reduce_kernel   sum_b (b+1) S_b by chunked running sums
-//   7. host                 sum_w 2^(cw) R_w  (<= 256 doublings)
+//   6. bucket_reduce_kernel / window_reduce_kernel   sum_b (b+1) S_b by chunked running sums; chunk offsets through
+//                           bit-plane sums of the chunk totals (MsmPlan in internal.hpp), not a scalar multiplication
+//   7. host                 recombine the planes per group, then sum_w 2^(cw) R_w  (<= 256 doublings)
 //
 // Steps 1-4 depend only on the scalars and are shared by every MSM over the same scalar
 // vector (a_query, b_g1_query, b_g2_query and l_query all use the witness: one sort, four
@@ -498,20 +499,26 @@ __global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw
         for (uint32_t q = 0; q < np; ++q) run.add(Acc30<F30>::load_raw(partials[t0 + q]));
         tot.add(run);
     }
-    // sum_b (b+1) S_b over the chunk = tot + b_lo * run
-    if (chunk_sum) run.store_raw(&chunk_sum[t]);   // merged plan: the group's plain sum is needed too
-    if (b_lo) tot.add(run.mul_small(b_lo));
+    // sum_b (b+1) S_b over the chunk = tot + b_lo * run: the b_lo * run part is assembled from bit-plane sums of `run` over
+    // the chunks by the window level and the host (MsmPlan) -- no scalar multiplication in this chain of dependent additions
+    run.store_raw(&chunk_sum[t]);
     tot.store_raw(&chunk_out[t]);
 }
 
+// grid = (groups, planes): plane 0 sums the chunks' weighted sums, plane 1 their plain sums, plane 2 + k the plain sums of the
+// chunks whose index has bit k set
 template <class F30>
-__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw<typename F30::Raw>* __restrict__ chunk_out, uint32_t cpw,
+__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw<typename F30::Raw>* __restrict__ chunk_out,
+                                                                    const AccRaw<typename F30::Raw>* __restrict__ chunk_sum, uint32_t cpw,
                                                                     XYZZ<typename F30::Std>* __restrict__ window_sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
-    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    const uint32_t w = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+    const AccRaw<typename F30::Raw>* src = (p == 0 ? chunk_out : chunk_sum) + (uint64_t)w * cpw;
+    const uint32_t mask = p >= 2 ? 1u << (p - 2) : 0u;
     Acc30<F30> acc = Acc30<F30>::identity();
-    for (uint32_t j = tid; j < cpw; j += WIN_THREADS) acc.add(Acc30<F30>::load_raw(chunk_out[(uint64_t)w * cpw + j]));
+    for (uint32_t j = tid; j < cpw; j += WIN_THREADS)
+        if (!mask || (j & mask)) acc.add(Acc30<F30>::load_raw(src[j]));
     acc.store_raw(&sh[tid]);
     __syncthreads();
     for (uint32_t d = WIN_THREADS / 2; d > 0; d >>= 1) {
@@ -522,8 +529,8 @@ __global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw
         }
         __syncthreads();
     }
-    // the W window sums are what leaves the device: standard arkworks Montgomery radix
-    if (tid == 0) window_sums[w] = Acc30<F30>::load_raw(sh[0]).to_std();
+    // the plane sums are what leaves the device: standard arkworks Montgomery radix
+    if (tid == 0) window_sums[(uint64_t)w * gridDim.y + p] = Acc30<F30>::load_raw(sh[0]).to_std();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -778,7 +785,7 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
     const uint32_t cpw = plan.B / G;
     Raw *partials = nullptr, *chunk_out = nullptr;
     G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
-    G16_TRY(arena.alloc_n((size_t)cpw * plan.outputs(), &chunk_out));   // (b+1)-weighted chunk sums, then (merged) plain chunk sums
+    G16_TRY(arena.alloc_n((size_t)cpw * plan.groups * 2, &chunk_out));   // weighted chunk sums, then plain chunk sums
     G16_TRY(arena.alloc_n((size_t)plan.outputs(), &out->window_sums));
     out->partials = partials;
     out->chunk_out = chunk_out;
@@ -815,13 +822,12 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     Raw* chunk_out = static_cast<Raw*>(buf.chunk_out);
     hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, partials, ss.task_off, ss.heavy);
     G16_LAUNCH_CHECK();
-    const bool sums = plan.outputs() > plan.groups;
-    Raw* chunk_sum = sums ? chunk_out + (size_t)cpw * plan.groups : nullptr;
+    Raw* chunk_sum = chunk_out + (size_t)cpw * plan.groups;
     hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st,
                        partials, ss.task_off, plan.B, plan.groups, G, chunk_out, chunk_sum);
     G16_LAUNCH_CHECK();
-    // chunk_out and chunk_sum are contiguous: one launch reduces outputs() rows of cpw chunks each
-    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.outputs()), dim3(WIN_THREADS), lds_win, st, chunk_out, cpw, buf.window_sums);
+    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.groups, plan.planes()), dim3(WIN_THREADS), lds_win, st, chunk_out, chunk_sum, cpw,
+                       buf.window_sums);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
@@ -836,21 +842,31 @@ int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st) {
 
 template <class F>
 XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
+    const int NP = plan.planes(), bits = plan.chunk_bits();
+    // per group: T = sum_b (b+1) S_b = P_0 + G * sum_k 2^k P_(2+k)
+    auto group_T = [&](int g) -> XYZZ<F> {
+        const XYZZ<F>* P = ws + (size_t)g * NP;
+        XYZZ<F> hi = XYZZ<F>::identity();
+        for (int k = bits - 1; k >= 0; --k) { hi = hi.dbl(); hi.add(P[2 + k]); }
+        for (uint32_t b = plan.chunk_buckets(); b > 1; b >>= 1) hi = hi.dbl();
+        hi.add(P[0]);
+        return hi;
+    };
     XYZZ<F> total = XYZZ<F>::identity();
     if (plan.merged) {
         // bucket value of (group q, bucket b) is q*B + b + 1:  sum = sum_q T_q + B * sum_q q S_q
         const int Q = plan.groups;
         if (Q > 1) {
             XYZZ<F> run = XYZZ<F>::identity();
-            for (int q = Q - 1; q >= 1; --q) { run.add(ws[Q + q]); total.add(run); }
+            for (int q = Q - 1; q >= 1; --q) { run.add(ws[(size_t)q * NP + 1]); total.add(run); }
             for (uint32_t b = plan.B; b > 1; b >>= 1) total = total.dbl();
         }
-        for (int q = 0; q < Q; ++q) total.add(ws[q]);
+        for (int q = 0; q < Q; ++q) total.add(group_T(q));
         return total;
     }
     for (int w = plan.W - 1; w >= 0; --w) {
         for (int k = 0; k < plan.c; ++k) total = total.dbl();
-        total.add(ws[w]);
+        total.add(group_T(w));
     }
     return total;
 }
