@@ -35,6 +35,10 @@ class UnexpectedIdentity(SynthesisError):
     """gamma or delta is zero (generator.rs:110-111)"""
 
 
+class InvalidData(G16Error):
+    """ark_serialize::SerializationError::InvalidData"""
+
+
 class QueryC(C.Structure):
     _fields_ = [("points", C.c_void_p), ("count", C.c_uint64), ("start", C.c_uint64)]
 
@@ -86,7 +90,7 @@ EXPORTS = [
     "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_finalize_host", "g16_get_timings", "g16_witness_map",
     "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
     "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version", "g16_generate_parameters",
-    "g16_host_qap_evaluations",
+    "g16_host_qap_evaluations", "g16_serialized_point_size", "g16_serialize_points", "g16_deserialize_points",
 ]
 
 
@@ -145,6 +149,10 @@ class Lib:
         c.g16_host_msm_model.argtypes = [C.c_int, C.c_int, u64p, u64p, C.c_uint64, C.c_int, u64p]
         c.g16_generate_parameters.argtypes = [C.c_void_p, C.POINTER(CsrViewC), C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(ToxicWasteC),
                                               u64p, u64p, C.POINTER(ParamsViewC)]
+        c.g16_serialized_point_size.restype = C.c_uint64
+        c.g16_serialized_point_size.argtypes = [C.c_int, C.c_int, C.c_int]
+        c.g16_serialize_points.argtypes = [C.c_int, C.c_int, C.c_int, u64p, C.c_uint64, C.c_char_p]
+        c.g16_deserialize_points.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_int, u64p]
         c.g16_host_qap_evaluations.argtypes = [C.c_int, C.POINTER(CsrViewC), C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p, u64p, u64p, u64p]
 
     def check(self, status: int):
@@ -158,6 +166,8 @@ class Lib:
             raise PolynomialDegreeTooLarge(status, msg)
         if status == 8:
             raise UnexpectedIdentity(status, msg)
+        if status == 9:
+            raise InvalidData(status, msg)
         raise G16Error(status, msg)
 
     def version(self) -> str:

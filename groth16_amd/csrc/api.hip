@@ -976,6 +976,19 @@ int g16_host_qap_evaluations(int curve, const g16_csr_view abc[3], uint64_t num_
     return G16_ERR_BAD_ARG;
 }
 
+uint64_t g16_serialized_point_size(int curve, int g2, int compressed) { return g16::serialized_point_size(curve, g2, compressed); }
+
+int g16_serialize_points(int curve, int g2, int compressed, const uint64_t* points, uint64_t n, uint8_t* out) {
+    if ((!points || !out) && n) return G16_ERR_BAD_ARG;
+    return g16::serialize_points(curve, g2, compressed, points, n, out);
+}
+
+int g16_deserialize_points(int curve, int g2, int compressed, const uint8_t* in, uint64_t n, int validate, uint64_t* points_out) {
+    if ((!in || !points_out) && n) return G16_ERR_BAD_ARG;
+    if (validate < 0 || validate > 2) return G16_ERR_BAD_ARG;
+    return g16::deserialize_points(curve, g2, compressed, in, n, validate, points_out);
+}
+
 const char* g16_strerror(int status) {
     switch (status) {
         case G16_OK: return "ok";
@@ -987,6 +1000,7 @@ const char* g16_strerror(int status) {
         case G16_ERR_NO_DEVICE: return "no HIP device";
         case G16_ERR_INTERNAL: return "internal error";
         case G16_ERR_UNEXPECTED_IDENTITY: return "unexpected identity: gamma or delta is zero";
+        case G16_ERR_INVALID_DATA: return "invalid data: the bytes do not encode a point of the group";
         default: return "unknown status";
     }
 }

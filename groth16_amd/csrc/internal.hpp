@@ -198,6 +198,11 @@ template <class C>
 int qap_evaluations_host(const g16_csr_view abc[3], uint64_t ni, uint64_t nc, uint64_t nv, const uint64_t* t, uint64_t* a_out, uint64_t* b_out,
                          uint64_t* c_out, uint64_t* zt_out);
 
+// ---- point (de)serialisation (serialize.hip; host only) -----------------------------------------------
+int serialize_points(int curve, int g2, int compressed, const uint64_t* points, uint64_t n, uint8_t* out);
+int deserialize_points(int curve, int g2, int compressed, const uint8_t* in, uint64_t n, int validate, uint64_t* points_out);
+uint64_t serialized_point_size(int curve, int g2, int compressed);
+
 // ---- synthetic generators (synth.hip) -----------------------------------------------------------
 template <class C> int synth_bases_device(int g2, uint64_t seed, uint64_t first, uint64_t n, void* out_dev, hipStream_t st);
 

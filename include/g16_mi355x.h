@@ -46,7 +46,8 @@ typedef enum {
     G16_ERR_OOM = 5,
     G16_ERR_NO_DEVICE = 6,
     G16_ERR_INTERNAL = 7,
-    G16_ERR_UNEXPECTED_IDENTITY = 8 /* SynthesisError::UnexpectedIdentity: gamma or delta is zero (generator.rs:110-111) */
+    G16_ERR_UNEXPECTED_IDENTITY = 8, /* SynthesisError::UnexpectedIdentity: gamma or delta is zero (generator.rs:110-111) */
+    G16_ERR_INVALID_DATA = 9         /* SerializationError::InvalidData: bytes that are not a point of the group        */
 } g16_status;
 
 typedef enum { G16_BLS12_381 = 0, G16_BN254 = 1 } g16_curve;
@@ -209,6 +210,19 @@ int g16_generate_parameters(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t nu
 int g16_host_qap_evaluations(int curve, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints,
                              uint64_t num_variables, const uint64_t t[4], uint64_t* a_out, uint64_t* b_out,
                              uint64_t* c_out, uint64_t zt_out[4]);
+
+/* ---- canonical (de)serialisation of points (CPU) ----
+ * The element format behind `#[derive(CanonicalSerialize, CanonicalDeserialize)]` on Proof / VerifyingKey / ProvingKey
+ * (src/data_structures.rs:8,31,125): BLS12-381 in the zcash / IETF form that ark-bls12-381 uses, BN254 in ark-ec's
+ * default short-Weierstrass form (see serialize.hip; restated from the published formats, not checkable against the
+ * reference here).  Containers (Vec<T> = u64 little-endian length + elements, struct = fields in order) are assembled by the
+ * caller (groth16_amd/serialize.py).  `points`: affine Montgomery limbs as everywhere in this ABI. */
+uint64_t g16_serialized_point_size(int curve, int g2, int compressed);
+int g16_serialize_points(int curve, int g2, int compressed, const uint64_t* points, uint64_t n, uint8_t* out);
+/* validate: 0 = Validate::No, 1 = on-curve check, 2 = on-curve + prime-order subgroup (Validate::Yes).
+ * G16_ERR_INVALID_DATA for a non-canonical coordinate, inconsistent flags, an x with no point, or a failed check */
+int g16_deserialize_points(int curve, int g2, int compressed, const uint8_t* in, uint64_t n, int validate,
+                           uint64_t* points_out);
 
 /* ---- host-side arithmetic self-test hooks (CPU; used by the `not gpu` tests) ----
  * The same field / group code the kernels use, compiled for the host.
