@@ -135,3 +135,28 @@ def test_malformed_input_is_rejected(cp):
     with pytest.raises(ValueError):
         ser.deserialize_points(cp.name, raw[:-1], 1, False, False, 0)
     assert g.Proof  # the type the round trips return
+
+
+def test_bulk_round_trip_uses_threads(orc):
+    """65 536 points (the threaded path of g16_serialize_points / g16_deserialize_points), compressed, Validate::No"""
+    import time
+
+    import groth16_amd.serialize as ser
+
+    cp = pm.BLS12_381
+    n = 1 << 16
+    pts = np.tile(orc.synth_bases(cp.name, False, 4, 1 << 10), (n >> 10, 1))
+    pts[12345] = 0                                 # an identity in the middle
+    t0 = time.time()
+    data = ser.serialize_points(cp.name, pts, False, True)
+    back = ser.deserialize_points(cp.name, data, n, False, True, validate=1)
+    assert (back == pts).all()
+    assert time.time() - t0 < 120
+    bad = bytearray(data)
+    bad[48 * 40000] ^= 0x1f                        # corrupt one x: with overwhelming probability no longer canonical / on the curve
+    from groth16_amd.binding import InvalidData
+    try:
+        out = ser.deserialize_points(cp.name, bytes(bad), n, False, True, validate=1)
+        assert not (out[40000] == pts[40000]).all()   # (the corrupted x happened to be another valid point)
+    except InvalidData:
+        pass
