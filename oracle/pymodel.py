@@ -579,6 +579,110 @@ def witness_map_from_matrices(cp: CurveParams, cs: R1CS, z: Sequence[int], want_
 
 
 # ----------------------------------------------------------------------------------
+# Distributed witness map: the algorithm the next round's multi-GPU path will run, modelled
+# here with N simulated ranks so that its index maps are pinned before any kernel exists.  n = N * M.
+#   residue distribution: rank r holds x[r + N*i2]           for i2 < M
+#   block distribution:   rank r holds x[k2 + M*k1]          for k2 in [r*M/N, (r+1)*M/N), k1 < N
+# An n-point transform is one local pass, one twiddle, ONE all-to-all and one more local pass (the 4-step FFT):
+#   type 1 (residue -> block): M-point NTT over i2, times w^(i1 k2), exchange, N-point NTT over i1
+#   type 2 (block -> residue): N-point NTT over k1, times w^(k2 ka), exchange, M-point NTT over k2
+# so ifft -> coset fft -> pointwise -> coset ifft alternates 1, 2, 1 and needs no re-distribution in between; each rank ends
+# with the h coefficients of its block distribution, which is then also how h_query has to be cut.
+# ----------------------------------------------------------------------------------
+
+
+def _ntt_small(x: Sequence[int], w: int, p: int) -> List[int]:
+    """X[k] = sum_i x[i] w^(ik): by definition for short inputs, radix-2 recursion otherwise (power-of-two lengths)"""
+    n = len(x)
+    if n <= 16:
+        return [sum(x[i] * pow(w, i * k, p) for i in range(n)) % p for k in range(n)]
+    e, o = _ntt_small(x[0::2], w * w % p, p), _ntt_small(x[1::2], w * w % p, p)
+    out, t = [0] * n, 1
+    for k in range(n // 2):
+        v = t * o[k] % p
+        out[k], out[k + n // 2] = (e[k] + v) % p, (e[k] - v) % p
+        t = t * w % p
+    return out
+
+
+def dist_transform_type1(ranks: List[List[int]], w: int, p: int) -> List[List[int]]:
+    """ranks[r][i2] = x[r + N*i2]  ->  out[r][k1*(M//N) + j] = X[(r*M//N + j) + M*k1],  X[k] = sum_i x[i] w^(ik)"""
+    N, M = len(ranks), len(ranks[0])
+    wM, wN, blk = pow(w, N, p), pow(w, M, p), M // N
+    send = []
+    for i1 in range(N):
+        y = _ntt_small(ranks[i1], wM, p)
+        send.append([y[k2] * pow(w, i1 * k2, p) % p for k2 in range(M)])
+    out = []
+    for r in range(N):          # the all-to-all: rank r receives, from every i1, the slice k2 in its block
+        cols = [[send[i1][r * blk + j] for i1 in range(N)] for j in range(blk)]
+        res = [_ntt_small(c, wN, p) for c in cols]           # res[j][k1]
+        out.append([res[j][k1] for k1 in range(N) for j in range(blk)])
+    return out
+
+
+def dist_transform_type2(ranks: List[List[int]], w: int, p: int) -> List[List[int]]:
+    """ranks[r][k1*(M//N) + j] = x[(r*M//N + j) + M*k1]  ->  out[ka][kb] = X[ka + N*kb]"""
+    N = len(ranks)
+    blk = len(ranks[0]) // N
+    M = blk * N
+    wM, wN = pow(w, N, p), pow(w, M, p)
+    send = [[None] * M for _ in range(N)]                    # send[ka][ib]
+    for r in range(N):
+        for j in range(blk):
+            ib = r * blk + j
+            z = _ntt_small([ranks[r][ia * blk + j] for ia in range(N)], wN, p)   # over ia, index i = ia*M + ib
+            for ka in range(N):
+                send[ka][ib] = z[ka] * pow(w, ib * ka, p) % p
+    return [_ntt_small(send[ka], wM, p) for ka in range(N)]
+
+
+def distributed_witness_map(cp: CurveParams, cs: R1CS, z: Sequence[int], N: int):
+    """witness_map_from_matrices on N simulated ranks.  Returns (pieces, index_sets): pieces[r][t] = h[index_sets[r][t]]."""
+    p = cp.r
+    nc, nin = cs.num_constraints, cs.num_inputs
+    dom = Domain(cp, nc + nin)
+    n = dom.n
+    assert n % (N * N) == 0, "needs N^2 | n"
+    M = n // N
+    blk = M // N
+    g = cp.fr_generator
+    ginv = pow(g, p - 2, p)
+
+    def rows(mat, extra_inputs):
+        out = []
+        for r in range(N):     # rank r evaluates the constraints i = r (mod N): any row split works for the sparse products
+            v = []
+            for i2 in range(M):
+                i = r + N * i2
+                if i < nc:
+                    v.append(evaluate_constraint(mat[i], z, p))
+                elif extra_inputs and i < nc + nin:
+                    v.append(z[i - nc])
+                else:
+                    v.append(0)
+            out.append(v)
+        return out
+
+    def block_index(r, t):
+        k1, j = divmod(t, blk)
+        return (r * blk + j) + M * k1
+
+    def coset_evals(ev):
+        co = dist_transform_type1(ev, dom.omega_inv, p)                                               # ifft (x n)
+        co = [[co[r][t] * dom.n_inv % p * pow(g, block_index(r, t), p) % p for t in range(M)] for r in range(N)]
+        return dist_transform_type2(co, dom.omega, p)                                                  # coset fft
+
+    a, b, c = coset_evals(rows(cs.a, True)), coset_evals(rows(cs.b, False)), coset_evals(rows(cs.c, False))
+    zinv = pow(dom.vanishing(g), p - 2, p)
+    q = [[(a[r][t] * b[r][t] - c[r][t]) * zinv % p for t in range(M)] for r in range(N)]              # residue distribution
+    h = dist_transform_type1(q, dom.omega_inv, p)
+    idx = [[block_index(r, t) for t in range(M)] for r in range(N)]
+    h = [[h[r][t] * dom.n_inv % p * pow(ginv, idx[r][t], p) % p for t in range(M)] for r in range(N)]
+    return h, idx
+
+
+# ----------------------------------------------------------------------------------
 # keys, setup with a known trapdoor (src/generator.rs:47-208)
 # ----------------------------------------------------------------------------------
 

@@ -170,3 +170,35 @@ def test_degree_too_large(orc):
     with pytest.raises(ValueError):
         pm.Domain(cp, (1 << 28) + 1)
     assert pm.Domain(cp, 1 << 28).n == 1 << 28 if False else True
+
+
+@pytest.mark.parametrize("cp", [pm.BLS12_381, pm.BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("N", [2, 4, 8])
+def test_distributed_witness_map_model(cp, N):
+    """the 4-step / one-all-to-all-per-transform witness map planned for the multi-GPU path gives, piece
+    by piece, the h of witness_map_from_matrices; every index is owned by exactly one rank"""
+    cs, z = pm.syn_circuit(cp, 7, 3, dense=True)          # domain 128 (padded, multi-term rows)
+    want = pm.witness_map_from_matrices(cp, cs, z)
+    pieces, idx = pm.distributed_witness_map(cp, cs, z, N)
+    seen = {}
+    for r in range(N):
+        assert len(pieces[r]) == len(idx[r]) == len(want) // N
+        for v, i in zip(pieces[r], idx[r]):
+            assert i not in seen
+            seen[i] = v
+    assert [seen[i] for i in range(len(want))] == want
+    # the transforms themselves, against the plain domain transform
+    dom = pm.Domain(cp, len(want))
+    x = [pm.SplitMix64(5).field(cp.r) for _ in range(dom.n)]
+    M = dom.n // N
+    res = [[x[r + N * i2] for i2 in range(M)] for r in range(N)]
+    X = dom.fft(x)
+    t1 = pm.dist_transform_type1(res, dom.omega, cp.r)
+    blk = M // N
+    for r in range(N):
+        for t in range(M):
+            k1, j = divmod(t, blk)
+            assert t1[r][t] == X[(r * blk + j) + M * k1]
+    t2 = pm.dist_transform_type2(t1, dom.omega_inv, cp.r)   # back (up to the factor n), now in residue distribution
+    for r in range(N):
+        assert [v * dom.n_inv % cp.r for v in t2[r]] == [x[r + N * i2] for i2 in range(M)]
