@@ -66,7 +66,10 @@ def _worker(rank, world, port, curve, q):
             n = min(len(bases), len(scalars))
             if n:
                 b, sc = np.ascontiguousarray(bases[:n]), np.ascontiguousarray(scalars[:n])
-                assert lb.c.g16_host_msm_model(CURVE_ID[curve], int(g2), ptr64(b), ptr64(sc), n, 0, ptr64(out)) == 0
+                # rank 0 models the per-window bucket scheme, rank 1 the merged-window scheme of a key held as window tables:
+                # partial sums are group elements, so ranks need not agree on how they computed them
+                c_win = 0 if rank == 0 else -10
+                assert lb.c.g16_host_msm_model(CURVE_ID[curve], int(g2), ptr64(b), ptr64(sc), n, c_win, ptr64(out)) == 0
             return _xyzz_from_affine(out, one_fq, g2)
 
         (a_lo, a_hi), (l_lo, l_hi), (h_lo, h_hi) = rg["a"], rg["l"], rg["h"]
