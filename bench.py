@@ -144,16 +144,20 @@ class DeviceProver:
                        ptr64(fx["a0"]), ptr64(fx["b10"]), ptr64(fx["b20"]), q(bufs["a"], a_lo, a_hi), q(bufs["b1"], a_lo, a_hi),
                        q(bufs["b2"], a_lo, a_hi), q(bufs["h"], h_lo, h_hi), q(bufs["l"], l_lo, l_hi), 1)
         self.pk = C.c_void_p()
+        torch.cuda.synchronize()
+        t_load = time.perf_counter()
         self.lib.check(c.g16_pk_load(self.ctx, C.byref(view), C.byref(self.pk)))
+        self.pk_load_s = time.perf_counter() - t_load   # the "cold" cost: window tables built from device-resident bases, once per key
         self.bufs = bufs  # standard-form copies kept for the CPU-baseline download (the library holds its own)
         # fixed non-zero r, s (zero-knowledge randomness is an input: prover.rs:173-178)
         self.r = z[2].copy()
         self.s = z[3].copy()
 
-    def partial(self):
+    def partial(self, host_z=None):
+        """host_z = None: the witness is already in HBM (the timed configuration); else a host pointer (int) to upload from"""
         part = PartialC()
-        self.lib.check(self.lib.c.g16_prove_partial(self.ctx, self.pk, self.ck, C.c_void_p(self.z_dev.data_ptr()), self.nvars, 1, 0,
-                                                    C.byref(part)))
+        zp = C.c_void_p(self.z_dev.data_ptr()) if host_z is None else C.c_void_p(host_z)
+        self.lib.check(self.lib.c.g16_prove_partial(self.ctx, self.pk, self.ck, zp, self.nvars, 1 if host_z is None else 0, 0, C.byref(part)))
         return part
 
     def finalize(self, parts):
@@ -194,15 +198,16 @@ def default_cpu_threads():
     return ncpu
 
 
-def cpu_baseline(curve, k_cpu, seed, threads, key="valid"):
+def cpu_baseline(curve, k_cpu, seed, threads, key="valid", reuse=None):
     """CPU oracle on a bounded sample: same circuit family / key shape at k_cpu; pk generated on the GPU and
-    downloaded so that GPU and CPU prove the very same instance (also a parity check of this bench)."""
+    downloaded so that GPU and CPU prove the very same instance (also a parity check of this bench).  `reuse`: the
+    benchmark's own DeviceProver when the sample IS the benchmark instance (--cpu-log2 == --log2)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import Csr, FlatCircuit, FlatPk, oracle
 
     orc = oracle()
     orc.set_threads(threads or default_cpu_threads())
-    dp = DeviceProver(curve, k_cpu, seed, 0, 1, torch.cuda.current_device(), key)
+    dp = reuse if reuse is not None else DeviceProver(curve, k_cpu, seed, 0, 1, torch.cuda.current_device(), key)
     gpu_proof = dp.finalize([dp.partial()])
     rp, cols, val = dp.csr_host
     ck = FlatCircuit(curve, dp.nin, dp.nc, dp.nvars, [Csr(rp, cols[i], val) for i in range(3)], dp.z_host)
@@ -220,7 +225,7 @@ def cpu_baseline(curve, k_cpu, seed, threads, key="valid"):
     dt = time.time() - t0
     match = bool((proof == gpu_proof).all())
     return dict(value=dp.nc / dt, unit="constraints/s", cores=orc.threads, kind="port",
-                sample=f"SYN(k={k_cpu}) BLS12-381, {dp.nc} constraints, one proof, {dt:.2f} s; C++ restatement of ark-groth16's "
+                sample=f"SYN(k={k_cpu}) {curve}, {dp.nc} constraints, one proof, {dt:.2f} s; C++ restatement of ark-groth16's "
                        f"CPU algorithm (oracle/g16_oracle.cpp), not ark-groth16 itself",
                 seconds=dt, phases={k_: round(v, 3) for k_, v in phases.items()}, gpu_proof_matches_cpu=match)
 
@@ -232,7 +237,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2", type=int, default=int(os.environ.get("G16_BENCH_LOG2", "22")))
     ap.add_argument("--curve", default="bls12_381")
-    ap.add_argument("--cpu-log2", type=int, default=int(os.environ.get("G16_BENCH_CPU_LOG2", "18")))
+    ap.add_argument("--cpu-log2", type=int, default=int(os.environ.get("G16_BENCH_CPU_LOG2", "20")),
+                    help="size of the CPU-baseline sample (2^20: ~10 s of CPU work; pass --cpu-log2 22 for the headline instance itself)")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("G16_BENCH_CPU_THREADS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--key", choices=["valid", "synthetic"], default=os.environ.get("G16_BENCH_KEY", "valid"),
@@ -323,6 +329,25 @@ def main():
         dist.all_gather(gathered, pt)
         assert all(bool((x == gathered[0]).all()) for x in gathered), "ranks disagree on the proof"
 
+    # PCIe-inclusive rates (SURVEY.md 8(d) defines the metric with the witness on the host at entry; `value` above is the
+    # HBM-resident rate the bench contract asks for): the same proof with full_assignment uploaded inside the call, from
+    # pageable and from pinned host memory.  Outside the timed region; single-GPU only.
+    h2d = None
+    if dist is None:
+        h2d = {}
+        z_pinned = torch.from_numpy(p.z_host.view(np.int64)).pin_memory()
+        for name, hp in (("pageable", p.z_host.ctypes.data), ("pinned", z_pinned.data_ptr())):
+            p.finalize([p.partial(hp)])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = max(2, min(args.steps, 5))
+            for _ in range(reps):
+                pr2 = p.finalize([p.partial(hp)])
+            torch.cuda.synchronize()
+            t_h = (time.perf_counter() - t1) / reps
+            assert (pr2 == proof).all(), "host-witness proof differs from the device-witness proof"
+            h2d[name] = dict(ms_per_step=1e3 * t_h, value=p.nc / t_h)
+
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = p.nc * args.steps / dt
@@ -353,7 +378,19 @@ def main():
             valu = dict(kind="v_mad_u64_u32 issue (integer VALU)", mads_per_launch=mads, achieved_Tmad_s=mads / (avg_ms * 1e-3) / 1e12,
                         measured_peak_Tmad_s=31.5, frac=mads / (avg_ms * 1e-3) / 31.5e12, window_bits=int(last_tm.get("window_bits", 0)),
                         windows=n_windows, points_folded_per_launch=n_pts * n_windows)
+        # second object for the transforms (2 * 32 * n algorithmic bytes per NTT, seven per proof), from the
+        # HIP-event timers around them inside the witness map
+        ntt_ms = phase_acc.get("ntt_ms", 0.0) / args.steps
+        roofline_ntt = None
+        if ntt_ms > 0:
+            ntt_bytes = 7 * 2 * 32 * p.n
+            roofline_ntt = dict(bound="hbm", achieved=ntt_bytes / (ntt_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, kernel="ntt30_* (7 radix-2 transforms of size n per proof)",
+                                ms_per_step=ntt_ms, algorithmic_bytes_per_step=ntt_bytes, traffic=None,
+                                note="Fr-product bound in practice (DESIGN.md 4.2); replicated on every rank when sharded")
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload; not measured in this run)" if traffic else None,
+                        binding_resource="integer VALU (v_mad_u64_u32 issue), not HBM: see valu_bound",
                         valu_bound=valu,
                         kernel="bucket_accumulate30_kernel (G1 Pippenger bucket pass)", launches_per_step=len(bucket_g1) // args.steps,
                         avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg_bytes,
@@ -368,9 +405,10 @@ def main():
                                    + ("valid proving key generated on the GPU from seeded toxic waste" if args.key == "valid"
                                       else "synthetic-bases proving key"),
                        "curve": args.curve, "log2_domain": args.log2, "constraints": p.nc, "key": args.key,
-                       "untimed_setup_s": round(t_setup, 2),
+                       "untimed_setup_s": round(t_setup, 2), "pk_load_s": round(p.pk_load_s, 3),
+                       "witness": "resident in HBM at entry (see value_incl_h2d for the PCIe-inclusive rates)",
                        "parallelism": f"msm-base-shard x{world}" if world > 1 else "single-gpu"},
-            "roofline": roofline,
+            "roofline": roofline, "roofline_ntt": roofline_ntt, "value_incl_h2d": h2d,
             "phases_ms_per_step": {k_: round(v / args.steps, 3) for k_, v in phase_acc.items()},
         }
         if os.environ.get("G16_BENCH_PRINT_PROOF"):
@@ -379,7 +417,8 @@ def main():
             out["proof_sha256"] = hashlib.sha256(proof.tobytes()).hexdigest()
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.curve, args.cpu_log2, 1, args.cpu_threads, args.key)
+                out["cpu_baseline"] = cpu_baseline(args.curve, args.cpu_log2, 1, args.cpu_threads, args.key,
+                                                   reuse=p if args.cpu_log2 == args.log2 else None)
             except Exception as e:  # noqa: BLE001 -- the baseline leg must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

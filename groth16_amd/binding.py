@@ -77,7 +77,7 @@ class PartialC(C.Structure):
 class TimingsC(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_a_ms", "msm_b_g1_ms", "msm_b_g2_ms", "scalar_prep_ms", "finish_ms",
-        "total_ms", "bucket_pass_ms")] + [("bucket_ms", C.c_double * 5), ("window_bits", C.c_double), ("windows", C.c_double)]
+        "total_ms", "bucket_pass_ms")] + [("bucket_ms", C.c_double * 5), ("window_bits", C.c_double), ("windows", C.c_double), ("ntt_ms", C.c_double)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "bucket_ms"}

@@ -66,10 +66,26 @@ struct g16_ctx {
                           // (G2: ~9 ms), so five of them side by side end sooner than one after the other
     Arena arena;
     g16_timings tm;
-    EventTimer t_wm, t_prep_h, t_prep_z, t_bucket[5];
+    EventTimer t_wm, t_prep_h, t_prep_z, t_bucket[5], t_ntt[2];
     hipEvent_t ev_z = nullptr, ev_h = nullptr, ev_wm = nullptr, ev_acc[5] = {}, ev_done[5] = {}, ev_msm_start[5] = {};
     void* pinned = nullptr;  // window sums land here (hipHostMalloc)
     size_t pinned_bytes = 0;
+};
+
+// Error exits of the entry points that launch on several streams: kernels still in flight reference arena memory that the
+// next call resets and reuses, so an early return first drains every stream of the ctx.
+struct DrainOnError {
+    g16_ctx* ctx;
+    bool armed = true;
+    explicit DrainOnError(g16_ctx* c) : ctx(c) {}
+    void dismiss() { armed = false; }
+    ~DrainOnError() {
+        if (!armed) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamSynchronize(ctx->stream3);
+        for (int i = 0; i < 5; ++i) (void)hipStreamSynchronize(ctx->red[i]);
+    }
 };
 
 struct g16_circuit {
@@ -252,8 +268,13 @@ struct Impl {
         auto fail = [&](int code) { circuit_free(dc); return code; };
         for (int m = 0; m < 3; ++m) {
             if (!abc[m].row_ptr) return fail(G16_ERR_BAD_ARG);
+            // a malformed CSR would send spmv3_kernel out of bounds on the device: row_ptr must start at 0 and never decrease
+            if (abc[m].row_ptr[0] != 0) return fail(G16_ERR_BAD_LENGTH);
+            for (uint64_t i = 0; i < num_constraints; ++i)
+                if (abc[m].row_ptr[i] > abc[m].row_ptr[i + 1]) return fail(G16_ERR_BAD_LENGTH);
             const uint64_t nnz = abc[m].row_ptr[num_constraints];
             dc->nnz[m] = nnz;
+            if (nnz && (!abc[m].col || !abc[m].val)) return fail(G16_ERR_BAD_ARG);
             for (uint64_t k = 0; k < nnz; ++k)
                 if (abc[m].col[k] >= num_variables) return fail(G16_ERR_BAD_LENGTH);
             if (hipMalloc((void**)&dc->row_ptr[m], (num_constraints + 1) * sizeof(uint64_t)) != hipSuccess) return fail(G16_ERR_OOM);
@@ -309,6 +330,7 @@ struct Impl {
             return G16_ERR_BAD_ARG;  // a / b_g1 / b_g2 must be sharded identically (they share one bucket sort)
         memset(out, 0, sizeof(*out));
         const double t_begin = now_ms();
+        DrainOnError drain(ctx);
         ctx->arena.reset();
         const Fr* d_z = nullptr;
         G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
@@ -321,7 +343,7 @@ struct Impl {
         G16_TRY(ctx->arena.alloc_n(n, &d_h));
         ScalarSort sort_h, sort_z, sort_l;
         G16_TRY(ctx->t_wm.start(s1));
-        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1)));
+        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1, ctx->t_ntt)));
         G16_TRY(ctx->t_wm.stop(s1));
         G16_HIP_TRY(hipEventRecord(ctx->ev_wm, s1));
 
@@ -413,6 +435,7 @@ struct Impl {
         G16_HIP_TRY(hipStreamSynchronize(s2));
         G16_HIP_TRY(hipStreamSynchronize(s3));
         for (int k = 0; k < 5; ++k) G16_HIP_TRY(hipStreamSynchronize(ctx->red[k]));
+        drain.dismiss();
         const double t_end = now_ms();
 
         g16_timings& tm = ctx->tm;
@@ -422,6 +445,7 @@ struct Impl {
             return hipEventElapsedTime(&t, ctx->ev_msm_start[k], ctx->ev_done[k]) == hipSuccess ? (double)t : 0.0;
         };
         tm.witness_map_ms = ctx->t_wm.ms();
+        tm.ntt_ms = ctx->t_ntt[0].ms() + ctx->t_ntt[1].ms();
         tm.scalar_prep_ms = ctx->t_prep_h.ms() + ctx->t_prep_z.ms();
         tm.msm_h_ms = span(0);
         tm.msm_l_ms = span(1);
@@ -530,6 +554,7 @@ struct Impl {
     static int witness_map_api(g16_ctx* ctx, const g16_circuit* ckh, const uint64_t* z, uint64_t n_assign, int on_device, uint64_t* h_out) {
         const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
         if (n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
+        DrainOnError drain(ctx);
         ctx->arena.reset();
         const Fr* d_z = nullptr;
         G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
@@ -538,6 +563,7 @@ struct Impl {
         G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, ctx->stream)));
         G16_HIP_TRY(hipMemcpyAsync(h_out, d_h, ck->dom->n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         G16_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        drain.dismiss();
         return G16_OK;
     }
 
@@ -546,6 +572,7 @@ struct Impl {
         typedef Affine<F> A;
         typedef XYZZ<F> X;
         hipStream_t st = ctx->stream;
+        DrainOnError drain(ctx);
         ctx->arena.reset();
         A* d_b = nullptr;
         Fr* d_s = nullptr;
@@ -579,6 +606,7 @@ struct Impl {
         std::vector<X> hws(ss.plan.outputs());
         G16_HIP_TRY(hipMemcpyAsync(hws.data(), buf.window_sums, sizeof(X) * ss.plan.outputs(), hipMemcpyDeviceToHost, st));
         G16_HIP_TRY(hipStreamSynchronize(st));
+        drain.dismiss();
         const A res = fold_windows<F>(hws.data(), ss.plan).to_affine();
         memcpy(out_affine, &res, sizeof(A));
         ctx->tm.bucket_pass_ms = ctx->t_bucket[0].ms();
@@ -806,7 +834,7 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream3);
     for (int i = 0; i < 5; ++i) (void)hipStreamSynchronize(ctx->red[i]);
     ctx->arena.release();
-    ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy();
+    ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy(); ctx->t_ntt[0].destroy(); ctx->t_ntt[1].destroy();
     for (int i = 0; i < 5; ++i) {
         ctx->t_bucket[i].destroy();
         (void)hipEventDestroy(ctx->ev_acc[i]); (void)hipEventDestroy(ctx->ev_done[i]); (void)hipEventDestroy(ctx->ev_msm_start[i]);

@@ -115,7 +115,7 @@ struct DeviceCircuit {
 };
 // d_z: full assignment on device; d_h: n Fr out (natural order).  Scratch comes from the arena.
 template <class C> int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, typename C::Fr* d_h, Arena& arena,
-                                          hipStream_t st);
+                                          hipStream_t st, EventTimer* ntt_timers = nullptr);
 
 // ---- MSM (msm.hip) ----------------------------------------------------------------------------
 struct MsmPlan {

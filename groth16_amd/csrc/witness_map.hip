@@ -52,7 +52,8 @@ __global__ void quotient_kernel(Fr* __restrict__ a, const Fr* __restrict__ b, co
 }
 
 template <class C>
-int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, typename C::Fr* d_h, Arena& arena, hipStream_t st) {
+int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, typename C::Fr* d_h, Arena& arena, hipStream_t st,
+                       EventTimer* ntt_timers) {
     typedef typename C::Fr Fr;
     const Domain<C>* dom = ck->dom;
     const size_t n = dom->n;
@@ -71,18 +72,23 @@ int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, ty
     hipLaunchKernelGGL((spmv3_kernel<Fr>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, st, args, d_z, ck->num_inputs,
                        ck->num_constraints, (uint64_t)n);
     G16_LAUNCH_CHECK();
+    // ntt_timers (optional, two of them): the six transforms of :201-207,220-221, then the seventh (:232) with its un-permute
+    if (ntt_timers) G16_TRY(ntt_timers[0].start(st));
     for (int m = 0; m < 3; ++m) {
         // ifft then coset fft (r1cs_to_qap.rs:201-207): inverse DIF, n^-1 g^bitrev(i), forward DIT
         G16_TRY((ntt_dif_dit<C>(dom, outs[m], /*dif_inverse=*/true, dom->s1_br, st)));
     }
+    if (ntt_timers) G16_TRY(ntt_timers[0].stop(st));
     hipLaunchKernelGGL((quotient_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, c, dom->zinv, n);
     G16_LAUNCH_CHECK();
+    if (ntt_timers) G16_TRY(ntt_timers[1].start(st));
     G16_TRY((ntt_dif<C>(dom, a, /*inverse=*/true, st)));
     G16_TRY((bitrev_scale<C>(dom, d_h, a, dom->s2, nullptr, st)));
+    if (ntt_timers) G16_TRY(ntt_timers[1].stop(st));
     return G16_OK;
 }
 
-template int witness_map_device<Bls12_381>(const DeviceCircuit<Bls12_381>*, const Bls12_381::Fr*, Bls12_381::Fr*, Arena&, hipStream_t);
-template int witness_map_device<Bn254>(const DeviceCircuit<Bn254>*, const Bn254::Fr*, Bn254::Fr*, Arena&, hipStream_t);
+template int witness_map_device<Bls12_381>(const DeviceCircuit<Bls12_381>*, const Bls12_381::Fr*, Bls12_381::Fr*, Arena&, hipStream_t, EventTimer*);
+template int witness_map_device<Bn254>(const DeviceCircuit<Bn254>*, const Bn254::Fr*, Bn254::Fr*, Arena&, hipStream_t, EventTimer*);
 
 }  // namespace g16

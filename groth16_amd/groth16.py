@@ -142,14 +142,21 @@ class _DevicePk:
             self.handle = C.c_void_p()
 
 
+def _csr_views(m: "ConstraintMatrices"):
+    """CsrViewC[3] over the three matrices plus the arrays the views point into.  A ctypes structure keeps only the raw
+    address: when a matrix arrives with another dtype or layout (e.g. scipy's int64 indptr) the normalised copy made here
+    is what the library reads, so the caller must hold the returned list until the C call has returned."""
+    keep = [(np.ascontiguousarray(x[0], dtype=np.uint64), np.ascontiguousarray(x[1], dtype=np.uint32), _c(x[2])) for x in (m.a, m.b, m.c)]
+    views = (CsrViewC * 3)(*[CsrViewC(ptr64(rp), ptr32(col), ptr64(val)) for rp, col, val in keep])
+    return views, keep
+
+
 class _DeviceCircuit:
     def __init__(self, ctx: _Ctx, m: ConstraintMatrices):
         self.ctx = ctx
         self.handle = C.c_void_p()
         self.num_variables = m.num_instance_variables + m.num_witness_variables
-        views = (CsrViewC * 3)(*[CsrViewC(ptr64(np.ascontiguousarray(x[0], dtype=np.uint64)), ptr32(np.ascontiguousarray(x[1], dtype=np.uint32)),
-                                          ptr64(_c(x[2]))) for x in (m.a, m.b, m.c)])
-        self._keep = (m.a, m.b, m.c)
+        views, self._keep = _csr_views(m)
         ctx.lib.check(ctx.lib.c.g16_circuit_load(ctx.handle, views, m.num_instance_variables, m.num_constraints, self.num_variables,
                                                  C.byref(self.handle)))
 
@@ -243,8 +250,7 @@ class Groth16:
         vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
         out = ParamsViewC(ptr64(pk.alpha_g1), ptr64(pk.beta_g1), ptr64(pk.delta_g1), ptr64(pk.beta_g2), ptr64(pk.delta_g2), ptr64(pk.gamma_g2),
                           ptr64(pk.gamma_abc_g1), vp(pk.a_query), vp(pk.b_g1_query), vp(pk.b_g2_query), vp(pk.h_query), vp(pk.l_query), 0)
-        views = (CsrViewC * 3)(*[CsrViewC(ptr64(np.ascontiguousarray(x[0], dtype=np.uint64)), ptr32(np.ascontiguousarray(x[1], dtype=np.uint32)),
-                                          ptr64(_c(x[2]))) for x in (matrices.a, matrices.b, matrices.c)])
+        views, keep = _csr_views(matrices)   # `keep` owns the (possibly converted) arrays until the call returns
         lb = self._ctx.lib
         lb.check(lb.c.g16_generate_parameters(self._ctx.handle, views, ni, matrices.num_constraints, nv, C.byref(tw),
                                               ptr64(_c(g1_generator).reshape(-1)), ptr64(_c(g2_generator).reshape(-1)), C.byref(out)))

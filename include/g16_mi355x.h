@@ -123,6 +123,8 @@ typedef struct {
     double bucket_ms[5];   /* that kernel per MSM: h, l, a, b_g1 (G1 kernel), b_g2 (G2 kernel); HIP events on the ctx stream */
     double window_bits;    /* Pippenger window size c of the witness MSMs in the last call ... */
     double windows;        /* ... and their window count W: a bucket pass folds (bases in the shard) * W points */
+    double ntt_ms;         /* the seven transforms of r1cs_to_qap.rs:201-232 alone (inside witness_map_ms, which also covers
+                              the three sparse mat-vecs and the pointwise pass) */
 } g16_timings;
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out);

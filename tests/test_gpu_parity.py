@@ -240,6 +240,46 @@ def test_proof_synthetic_bases(env, orc, g, k):
     assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
 
 
+def test_proof_domain_2_and_4(env, orc, g):
+    """SURVEY.md 8(d) edge domains: n = 2 (one constraint, no public input: only the constant-one instance variable) and
+    n = 4; the NTT kernels' smallest shapes and empty input_assignment slices (prover.rs:44-45)"""
+    curve, prover = env
+    cp = CP[curve]
+    p = cp.r
+    w0, w1 = pm.SplitMix64(3).field(p), pm.SplitMix64(4).field(p)
+    tiny = (pm.R1CS(1, 3, [[(1, 1)]], [[(1, 2)]], [[(1, 3)]]), [1, w0, w1, w0 * w1 % p])
+    for cs, z in (tiny, pm.syn_circuit(cp, 2, 9)):
+        pk, _ = pm.generate_parameters(cp, cs, 7)
+        r, s = pm.SplitMix64(1).field(p), pm.SplitMix64(2).field(p)
+        pr = pm.create_proof_with_reduction_and_matrices(cp, pk, r, s, cs, z)
+        ck, fpk = circuit_from_pymodel(cp, cs, z), pk_from_pymodel(cp, pk)
+        assert ck.domain_size == (2 if cs is tiny[0] else 4)
+        gm = mats_of(g, ck)
+        h = prover.witness_map_from_matrices(gm, ck.num_inputs, ck.num_constraints, ck.z)
+        assert (h == orc.witness_map(ck)).all()
+        proof = prover.create_proof_with_reduction_and_matrices(pk_of(g, fpk), ints_to_mont([r], p, 4)[0], ints_to_mont([s], p, 4)[0], gm,
+                                                                ck.num_inputs, ck.num_constraints, ck.z)
+        assert arr_to_g1(proof.a, cp)[0] == pr.a and arr_to_g2(proof.b, cp)[0] == pr.b and arr_to_g1(proof.c, cp)[0] == pr.c
+
+
+@pytest.mark.parametrize("scheme", [{}, {"G16_MSM_PRECOMP": "0"}], ids=["tables", "plain_bases"])
+def test_proof_half_identity_key(env, orc, g, scheme, monkeypatch):
+    """SURVEY.md 8(d) robustness input: 50 % identity bases in every query of the key (real keys hold many:
+    generator.rs:102-108), full proof against the oracle on the same key"""
+    curve, prover = env
+    for k_, v in scheme.items():
+        monkeypatch.setenv(k_, v)
+    ck = orc.syn_circuit(curve, 12, 4)
+    pk = orc.synth_pk(ck, 5)
+    rs = np.random.RandomState(7)
+    for name in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query"):
+        q = getattr(pk, name)
+        q[rs.rand(len(q)) < 0.5] = 0
+    r, s = orc.rand_fr(curve, 51, 1)[0], orc.rand_fr(curve, 52, 1)[0]
+    proof = prover.create_proof_with_reduction_and_matrices(pk_of(g, pk), r, s, mats_of(g, ck), ck.num_inputs, ck.num_constraints, ck.z)
+    assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+
+
 def test_sharded_proof_equals_single(env, orc, g):
     """MSM base sharding: 3 shards on one GPU, partial records combined by prove_finalize"""
     curve, prover = env
