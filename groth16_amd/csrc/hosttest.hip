@@ -2,6 +2,8 @@
 // Host-only translation unit (kept apart from api.hip so that the two build in parallel); exported as g16_host_selftest.
 #include "internal.hpp"
 #include "fp30.hpp"
+#include "batch_affine.hpp"
+#include <vector>
 
 using namespace g16;
 
@@ -84,10 +86,102 @@ struct SelfTest {
         return 0;
     }
 
+    // batched-affine arithmetic (batch_affine.hpp): the division-step inverse against Fermat's, the lane-pair Fq2 inverse, and
+    // the tree levels themselves -- AffineLevel::run executed lane by lane on the CPU over a padded, bucket-sorted entry list
+    // with every exceptional pair in it (identity bases, P + P at level 0 and at level 1, P + (-P), holes), compared bucket
+    // by bucket with XYZZ accumulation in the standard field
+    static int selftest_affine(uint64_t seed, int iters) {
+        typedef ModInv30<typename Fq::Params> MI;
+        uint64_t st = seed ^ 0xA1;
+        for (int it = 0; it < iters; ++it) {
+            Fq x = rand_fq(st);
+            if (it == 0) x = Fq::one();
+            if (it == 1) x = Fq::zero() - Fq::one();
+            if (x.is_zero()) continue;
+            F30 a = to30(x);
+            if (it % 3 == 1) { const F30 z = F30::zero(); a = a.add(z.template sub<8>(z)); }   // a lazy representative, + 8p
+            if (!(MI::inverse(a).to_std() == x.inverse())) return 6001;
+            const Fq y = rand_fq(st);
+            const Fq2 r = Fq2{x, y}.inverse();
+            if (!(pair_inverse<typename Fq::Params>(false, to30(x), to30(y)).to_std() == r.c0)) return 6002;
+            if (!(pair_inverse<typename Fq::Params>(true, to30(y), to30(x)).to_std() == r.c1)) return 6003;
+        }
+        const int NP = 150, NB = 90;
+        std::vector<G1A> pts, pts30;
+        const G1A gen = C::g1_generator();
+        G1X runp = G1X::from_affine(gen);
+        for (int i = 0; i < NP; ++i) {
+            const uint32_t k[1] = {(uint32_t)(sm_next(st) | 1)};
+            pts.push_back(runp.mul_bits(k, 32).to_affine());
+            runp.add_affine(gen);
+        }
+        pts[7] = G1A::identity();
+        pts[8] = G1A::identity();
+        for (const auto& p : pts) pts30.push_back(G1A{F30::std_to_r30(p.x), F30::std_to_r30(p.y)});
+        for (int R = 1; R <= 4; ++R) {
+            for (uint32_t K : {1u, 8u}) {
+                const uint32_t pad = 1u << R;
+                std::vector<uint32_t> sorted, off(NB + 1);
+                std::vector<G1X> ref(NB, G1X::identity());
+                for (int b = 0; b < NB; ++b) {
+                    off[b] = (uint32_t)sorted.size();
+                    int m = (int)(sm_next(st) % 40);
+                    if (b % 17 == 0) m = 0;
+                    if (b == 5) m = 1;
+                    std::vector<uint32_t> e;
+                    for (int i = 0; i < m; ++i) e.push_back((uint32_t)(sm_next(st) % NP) | ((uint32_t)(sm_next(st) & 1) << 31));
+                    if (m >= 4 && b % 3 == 0) e[1] = e[0];                                          // P + P
+                    if (m >= 4 && b % 3 == 1) e[3] = e[2] ^ 0x80000000u;                            // P + (-P)
+                    if (m >= 8 && b % 5 == 0) { e[4] = e[0]; e[5] = e[1]; e[6] = e[2]; e[7] = e[3]; }   // equal sums one level up
+                    if (m >= 2 && b % 7 == 0) { e[0] = 7; e[1] = 8; }                               // identity bases
+                    for (uint32_t v : e) {
+                        sorted.push_back(v);
+                        G1A q = pts[v & 0x7fffffffu];
+                        if (v >> 31) q = q.neg();
+                        ref[b].add_affine(q);
+                    }
+                    while (sorted.size() % pad) sorted.push_back(SORT_HOLE);
+                }
+                off[NB] = (uint32_t)sorted.size();
+                const uint32_t S = (uint32_t)sorted.size();
+                std::vector<G1A> la(S / 2 + 1), lb(S / 4 + 1);
+                const uint32_t maxw = (S / 2 + K * 64 - 1) / (K * 64) + 1;
+                std::vector<Word4> prefix((size_t)maxw * K * AffineLevel<F30, true>::QUADS * 64);
+                AffineLevelArgs<F30> a;
+                a.sorted = sorted.data(); a.total = &S; a.prefix = prefix.data(); a.shift = 0; a.base_count = NP; a.merged = 0; a.K = K;
+                const G1A* cur = pts30.data();
+                G1A* outs[2] = {la.data(), lb.data()};
+                for (int lvl = 0; lvl < R; ++lvl) {
+                    a.in = cur; a.out = outs[lvl & 1]; a.level = (uint32_t)lvl;
+                    for (uint32_t w = 0; w < maxw; ++w)
+                        for (uint32_t l = 0; l < 64; ++l) {
+                            if (lvl == 0) AffineLevel<F30, true>::run(a, w, l);
+                            else AffineLevel<F30, false>::run(a, w, l);
+                        }
+                    cur = a.out;
+                }
+                for (int b = 0; b < NB; ++b) {
+                    G1X acc = G1X::identity();
+                    for (uint32_t q = off[b] >> R; q < (off[b + 1] >> R); ++q) {
+                        const G1A p = cur[q];
+                        if (p.is_identity()) continue;
+                        acc.add_affine(G1A{F30::unpack(p.x.v).to_std(), F30::unpack(p.y.v).to_std()});
+                    }
+                    if (!(acc.to_affine() == ref[b].to_affine())) return 6100 + R * 10 + (int)K;
+                }
+            }
+        }
+        return 0;
+    }
+
     static int selftest30(uint64_t seed, int iters) {
         uint64_t st = seed;
         {
             const int rc = selftest_fr30(seed, iters);
+            if (rc) return rc;
+        }
+        {
+            const int rc = selftest_affine(seed, iters);
             if (rc) return rc;
         }
         for (int it = 0; it < iters; ++it) {

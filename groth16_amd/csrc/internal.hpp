@@ -128,7 +128,11 @@ struct MsmPlan {
     int groups = 0;
     bool merged = false;
     uint32_t B = 0;     // buckets per group
-    uint32_t Lmax = 0;  // segment length: sorted entries one bucket-pass lane walks (power of two)
+    uint32_t Lmax = 0;  // segment length: entries one bucket-pass lane walks (power of two)
+    // Batched-affine plan (batch_affine.hpp): R > 0 pads every bucket region of the sorted list to a multiple of 2^R entries
+    // (holes = the identity); R levels of pairwise affine additions with one shared inversion per lane batch then shrink the
+    // list 2^R-fold before the XYZZ bucket pass walks what is left (<= ceil(m / 2^R) points per bucket of m entries).
+    int affine_levels = 0;
     uint32_t chunk = 0; // points per histogram/scatter block
     uint32_t K[10];     // signed-digit bias  sum_w 2^(c-1) 2^(cw)
     uint32_t buckets() const { return B * (uint32_t)groups; }
@@ -161,7 +165,8 @@ struct ScalarSort {
     uint32_t* task_off = nullptr;  // [buckets + 1] exclusive prefix of per-bucket partial-sum slots (one per segment a bucket touches)
     uint32_t* heavy = nullptr;     // [0] = number of buckets with more than HEAVY_PARTS partials, then their ids
     uint32_t max_tasks = 0;        // host-side upper bound on task_off[buckets] (partial slots)
-    uint32_t max_segments = 0;     // host-side upper bound on ceil(sorted entries / Lmax)
+    uint32_t max_segments = 0;     // host-side upper bound on ceil(entries the bucket pass walks / Lmax)
+    uint64_t max_sorted = 0;       // host-side upper bound on offsets[buckets]: entries + padding of the batched-affine plan
 };
 template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Arena& arena, hipStream_t st, ScalarSort* out);
 

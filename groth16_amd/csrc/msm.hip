@@ -42,6 +42,7 @@
 #include "internal.hpp"
 #include "msm_common.hpp"
 #include "fp30.hpp"
+#include "batch_affine.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -260,12 +261,14 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* sh, ui
     return incl - v;
 }
 
-static __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ vals, uint32_t M,
+// `pad` (a power of two minus one, or 0): every value is rounded up to a multiple of pad + 1 before it is summed -- bucket
+// regions of the batched-affine plan start and end on multiples of 2^R entries
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ vals, uint32_t M, uint32_t pad,
                                                                        uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t sa[SCAN_THREADS];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
     uint32_t sum = 0, tot;
-    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) sum += (base + j < M) ? vals[base + j] : 0u;
+    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) sum += (base + j < M) ? ((vals[base + j] + pad) & ~pad) : 0u;
     (void)block_exclusive(sum, sa, &tot);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
@@ -285,12 +288,12 @@ static __global__ __launch_bounds__(SCAN_THREADS) void scan_block_offsets_kernel
     if (threadIdx.x == 0) prefix[M] = carry;
 }
 
-static __global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const uint32_t* __restrict__ vals, uint32_t M,
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const uint32_t* __restrict__ vals, uint32_t M, uint32_t pad,
                                                                   const uint32_t* __restrict__ block_base, uint32_t* __restrict__ prefix) {
     __shared__ uint32_t sa[SCAN_THREADS];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
     uint32_t cv[SCAN_PER_THREAD], sum = 0, tot;
-    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) { cv[j] = (base + j < M) ? vals[base + j] : 0u; sum += cv[j]; }
+    G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) { cv[j] = (base + j < M) ? ((vals[base + j] + pad) & ~pad) : 0u; sum += cv[j]; }
     uint32_t a = block_base[blockIdx.x] + block_exclusive(sum, sa, &tot);
     G16_UNROLL for (int j = 0; j < SCAN_PER_THREAD; ++j) {
         if (base + j < M) { prefix[base + j] = a; a += cv[j]; }
@@ -298,11 +301,12 @@ static __global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const u
 }
 
 // partial-sum slots of bucket b = number of length-L segments of the sorted list its entries touch
-static __global__ void bucket_slots_kernel(const uint32_t* __restrict__ offsets, uint32_t M, uint32_t lseg_log, uint32_t* __restrict__ nparts,
-                                    uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
+// (batched-affine plan: the bucket pass walks the level-R list, whose bucket regions are offsets >> R)
+static __global__ void bucket_slots_kernel(const uint32_t* __restrict__ offsets, uint32_t M, uint32_t off_shift, uint32_t lseg_log,
+                                    uint32_t* __restrict__ nparts, uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= M) return;
-    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    const uint32_t lo = offsets[b] >> off_shift, hi = offsets[b + 1] >> off_shift;
     const uint32_t np = hi > lo ? (((hi - 1) >> lseg_log) - (lo >> lseg_log) + 1u) : 0u;
     nparts[b] = np;
     if (np > HEAVY_PARTS) heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
@@ -350,22 +354,25 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(con
 // is flushed -- raw lazy limbs, no conversion -- into that bucket's slot for this segment (slot offsets from the scan),
 // so a bucket ends up with one partial sum per segment it touches; the reduction kernels add them up.
 // `bases` hold canonical x*R', y*R' packed in 32-bit words (convert_bases30_kernel).
-template <class F30>
+// DIRECT (batched-affine plan): the walk is over the level-R list itself -- slot e holds an affine point (or the identity),
+// bucket b owns slots [offsets[b] >> off_shift, offsets[b + 1] >> off_shift) -- instead of over sorted entry words.
+template <class F30, bool DIRECT>
 __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(
     const Affine<typename F30::Std>* __restrict__ bases, int64_t shift, uint64_t base_count, const uint32_t* __restrict__ sorted,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ slot_off, uint32_t M, uint32_t lseg_log, uint32_t merged,
-    AccRaw<typename F30::Raw>* __restrict__ partials) {
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ slot_off, uint32_t M, uint32_t off_shift, uint32_t lseg_log,
+    uint32_t merged, AccRaw<typename F30::Raw>* __restrict__ partials) {
     const uint32_t t = (blockIdx.x * ACC_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
-    const uint32_t S = offsets[M];                                                          // sorted entries in total
-    const uint32_t start = t << lseg_log;
-    if (start >= S) return;
-    const uint32_t end = min(S, start + (1u << lseg_log));
+    const uint32_t S = offsets[M] >> off_shift;                                            // entries in total
+    const uint64_t start64 = (uint64_t)t << lseg_log;
+    if (start64 >= S) return;
+    const uint32_t start = (uint32_t)start64;
+    const uint32_t end = (uint32_t)min((uint64_t)S, start64 + (1u << lseg_log));
     uint32_t lo = 0, hi = M;  // bucket containing `start`: offsets[lo] <= start < offsets[lo + 1]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (offsets[mid] <= start) lo = mid; else hi = mid;
+        if ((offsets[mid] >> off_shift) <= start) lo = mid; else hi = mid;
     }
-    uint32_t b = lo, b_first = offsets[b], b_end = offsets[b + 1];
+    uint32_t b = lo, b_first = offsets[b] >> off_shift, b_end = offsets[b + 1] >> off_shift;
     Acc30<F30> acc = Acc30<F30>::identity();
     // software pipeline: the base point of entry e+1 is gathered (and the sorted word of entry e+2 loaded) before the
     // ~20k-instruction addition of entry e, so the HBM latencies hide under arithmetic.  (Touching the cache lines of
@@ -381,20 +388,20 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         *at = (int64_t)row + idx;
         return idx >= 0 && (uint64_t)idx < base_count;
     };
-    auto fetch = [&](uint32_t v) {
-        v_next = v;
-        int64_t at;
-        ok_next = decode(v, &at);
+    auto fetch = [&](uint32_t v) {   // DIRECT: v is the slot index itself
+        v_next = DIRECT ? 0u : v;
+        int64_t at = (int64_t)v;
+        ok_next = DIRECT ? true : decode(v, &at);
         if (ok_next) ok_next = F30::load_point(bases, at, px_next, py_next);
     };
-    fetch(sorted[start]);
-    uint32_t v_fetch = start + 1 < end ? sorted[start + 1] : 0u;   // entry e+1's word, loaded one iteration early
+    fetch(DIRECT ? start : sorted[start]);
+    uint32_t v_fetch = DIRECT ? start + 1 : (start + 1 < end ? sorted[start + 1] : 0u);   // entry e+1's word, loaded one iteration early
     for (uint32_t e = start; e < end; ++e) {
         if (e == b_end) {  // crossed into the next non-empty bucket: flush this segment's share of bucket b
             acc.store_raw(&partials[slot_off[b] + (t - (b_first >> lseg_log))]);
             acc = Acc30<F30>::identity();
-            do { ++b; b_end = offsets[b + 1]; } while (b_end <= e);
-            b_first = offsets[b];
+            do { ++b; b_end = offsets[b + 1] >> off_shift; } while (b_end <= e);
+            b_first = offsets[b] >> off_shift;
         }
         const uint32_t v = v_next;
         const F30 px = px_next;
@@ -402,7 +409,8 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         const bool ok = ok_next;
         auto advance = [&]() {
             if (e + 1 < end) fetch(v_fetch);
-            v_fetch = e + 2 < end ? sorted[e + 2] : 0u;
+            if constexpr (DIRECT) v_fetch = e + 2;
+            else v_fetch = e + 2 < end ? sorted[e + 2] : 0u;
         };
         if constexpr (F30::ACC_PREFETCH) advance();
         if (ok) {
@@ -412,6 +420,16 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         if constexpr (!F30::ACC_PREFETCH) advance();
     }
     acc.store_raw(&partials[slot_off[b] + (t - (b_first >> lseg_log))]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5a. batched-affine tree levels (batch_affine.hpp): one launch per level, AFF_THREADS / 64 waves per workgroup
+// ---------------------------------------------------------------------------------------------
+static constexpr int AFF_THREADS = 128;
+template <class F30, bool LEVEL0>
+__global__ __launch_bounds__(AFF_THREADS, 2) void affine_level_kernel(AffineLevelArgs<F30> args) {
+    const uint32_t wave = (blockIdx.x * AFF_THREADS + threadIdx.x) >> 6;
+    AffineLevel<F30, LEVEL0>::run(args, wave, threadIdx.x & 63u);
 }
 
 template <class P> G16_HD Fp<P> to_r30(const Fp<P>& x) { return Fp30<P>::std_to_r30(x); }
@@ -642,7 +660,21 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
         plan->B = 1u << (c - 1);
         plan->groups = W;
     }
-    const uint64_t entries = n * (uint64_t)W;
+    const uint64_t all_entries = n * (uint64_t)W;
+    // batched-affine levels: they pay when buckets are long (each level halves a bucket's entries at ~0.6 of the XYZZ cost
+    // per addition, but a lane needs >= ~16 pairs to amortise its inversion and the chip >= ~2 k waves to stay busy)
+    plan->affine_levels = 0;
+    {
+        const uint64_t mean_load = all_entries / plan->buckets();
+        int R = (plan->merged && mean_load >= 24 && all_entries >= (8ull << 20)) ? 3 : 0;
+        if (const char* e = getenv("G16_MSM_AFFINE_LEVELS")) {   // 0 disables, 1..4 forces (tests run it at tiny sizes)
+            const int v = atoi(e);
+            if (v >= 0 && v <= 4) R = v;
+        }
+        if (all_entries + (uint64_t)plan->buckets() * ((1u << R) - 1u) >= ((uint64_t)1 << 32)) R = 0;
+        plan->affine_levels = R;
+    }
+    const uint64_t entries = (all_entries >> plan->affine_levels) + (plan->affine_levels ? plan->buckets() : 0);   // what the bucket pass walks
     // segment length of the bucket pass: 64 entries per lane (a pass ends with one partly filled round of segments, ~1/2
     // segment time on average: 64 measured 1 % faster than 128 at 2^22, 256 is 13 % slower, 32 drowns in partial sums),
     // shorter for small inputs so that the pass still has >= ~4 segments per lane slot of the chip
@@ -703,8 +735,17 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     G16_TRY(arena.alloc_n((size_t)M + 1, &out->offsets));
     G16_TRY(arena.alloc_n((size_t)M + 1, &out->task_off));
     G16_TRY(arena.alloc_n((size_t)M, &nparts));
-    G16_TRY(arena.alloc_n(nw ? nw : 1, &out->sorted));
-    out->max_segments = (uint32_t)((nw + plan.Lmax - 1) / plan.Lmax);
+    // batched-affine plan: every bucket region is padded to a multiple of 2^R entries; the padding slots keep the hole
+    // word the list is pre-filled with, and the bucket pass walks the level-R list (1 / 2^R of the slots)
+    const int R = plan.affine_levels;
+    const uint32_t pad = (1u << R) - 1u;
+    const uint64_t max_sorted = nw + (uint64_t)M * pad;
+    if (max_sorted >= ((uint64_t)1 << 32)) return G16_ERR_BAD_LENGTH;
+    out->max_sorted = max_sorted;
+    G16_TRY(arena.alloc_n(max_sorted ? max_sorted : 1, &out->sorted));
+    if (R) G16_HIP_TRY(hipMemsetAsync(out->sorted, 0xff, max_sorted * sizeof(uint32_t), st));   // SORT_HOLE
+    const uint64_t walked = R ? (max_sorted >> R) : nw;
+    out->max_segments = (uint32_t)((walked + plan.Lmax - 1) / plan.Lmax);
     out->max_tasks = out->max_segments + M;   // a bucket gets one slot per segment it touches: <= segments + buckets in total
     G16_HIP_TRY(hipMemsetAsync(counts, 0, ((size_t)2 * M + 1) * sizeof(uint32_t), st));
     PlanDev pd;
@@ -729,13 +770,13 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     const uint32_t lseg_log = (uint32_t)ilog2(plan.Lmax);
     const uint32_t max_scan = std::max(M, plan.merged ? Q * nb : 0u);
     G16_TRY(arena.alloc_n((size_t)(max_scan + SCAN_TILE - 1) / SCAN_TILE, &block_sums));
-    auto prefix_scan = [&](const uint32_t* vals, uint32_t* prefix, uint32_t count) -> int {
+    auto prefix_scan = [&](const uint32_t* vals, uint32_t* prefix, uint32_t count, uint32_t padmask = 0) -> int {
         const uint32_t nblocks = (count + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, count, block_sums);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, count, padmask, block_sums);
         G16_LAUNCH_CHECK();
         hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nblocks, count, prefix);
         G16_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, count, block_sums, prefix);
+        hipLaunchKernelGGL(scan_write_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, st, vals, count, padmask, block_sums, prefix);
         G16_LAUNCH_CHECK();
         return G16_OK;
     };
@@ -758,8 +799,9 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
         }
         G16_LAUNCH_CHECK();
     }
-    G16_TRY(prefix_scan(counts, out->offsets, M));
-    hipLaunchKernelGGL(bucket_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, out->offsets, M, lseg_log, nparts, out->heavy);
+    G16_TRY(prefix_scan(counts, out->offsets, M, pad));
+    hipLaunchKernelGGL(bucket_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, out->offsets, M, (uint32_t)R, lseg_log, nparts,
+                       out->heavy);
     G16_LAUNCH_CHECK();
     G16_TRY(prefix_scan(nparts, out->task_off, M));
     if (n) {
@@ -783,18 +825,65 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
     const uint32_t M = plan.buckets();
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
+    const int R = plan.affine_levels;
     Raw *partials = nullptr, *chunk_out = nullptr;
     G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
     G16_TRY(arena.alloc_n((size_t)cpw * plan.groups * 2, &chunk_out));   // weighted chunk sums, then plain chunk sums
     G16_TRY(arena.alloc_n((size_t)plan.outputs(), &out->window_sums));
     out->partials = partials;
     out->chunk_out = chunk_out;
+    // batched-affine levels: two ping-pong lists (level 1 holds max_sorted / 2 points, level 2 a quarter, level 3 reuses the
+    // first, ...) and the prefix-product scratch of the widest level
+    Affine<F>* lists[2] = {nullptr, nullptr};
+    Word4* prefix = nullptr;
+    constexpr uint32_t T = 64 / F30::LANES_PER_TASK;
+    constexpr int QUADS = AffineLevel<F30, true>::QUADS;
+    auto level_K = [&](int r) -> uint32_t {   // steps per task: as many as keep >= ~2 k waves in flight, 8 .. 64
+        const uint64_t pairs = ss.max_sorted >> (r + 1);
+        uint32_t K = 64;
+        while (K > 8 && pairs / ((uint64_t)K * T) < 2048) K >>= 1;
+        return K;
+    };
+    auto level_waves = [&](int r) -> uint64_t { return ((ss.max_sorted >> (r + 1)) + (uint64_t)level_K(r) * T - 1) / ((uint64_t)level_K(r) * T); };
+    if (R && ss.max_sorted) {
+        G16_TRY(arena.alloc_n((size_t)(ss.max_sorted >> 1) + 1, &lists[0]));
+        if (R > 1) G16_TRY(arena.alloc_n((size_t)(ss.max_sorted >> 2) + 1, &lists[1]));
+        size_t recs = 0;
+        for (int r = 0; r < R; ++r) recs = std::max(recs, (size_t)(level_waves(r) * level_K(r)) * QUADS * 64);
+        G16_TRY(arena.alloc_n(recs ? recs : 1, &prefix));
+    }
     if (bucket_timer) G16_TRY(bucket_timer->start(st));
+    const Affine<F>* walk = d_bases;
+    if (R && ss.max_sorted) {
+        AffineLevelArgs<F30> a;
+        a.sorted = ss.sorted;
+        a.total = ss.offsets + M;
+        a.prefix = prefix;
+        a.shift = shift;
+        a.base_count = base_count;
+        a.merged = plan.merged ? 1u : 0u;
+        for (int r = 0; r < R; ++r) {
+            a.in = r == 0 ? d_bases : lists[(r - 1) & 1];
+            a.out = lists[r & 1];
+            a.level = (uint32_t)r;
+            a.K = level_K(r);
+            const uint64_t waves = level_waves(r);
+            const unsigned blocks = (unsigned)((waves * 64 + AFF_THREADS - 1) / AFF_THREADS);
+            if (r == 0) hipLaunchKernelGGL((affine_level_kernel<F30, true>), dim3(blocks), dim3(AFF_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((affine_level_kernel<F30, false>), dim3(blocks), dim3(AFF_THREADS), 0, st, a);
+            G16_LAUNCH_CHECK();
+        }
+        walk = lists[(R - 1) & 1];
+    }
     if (ss.max_segments) {
         const uint64_t lanes = (uint64_t)ss.max_segments * F30::LANES_PER_TASK;
-        hipLaunchKernelGGL((bucket_accumulate30_kernel<F30>), dim3((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
-                           st, d_bases, shift, base_count, ss.sorted, ss.offsets, ss.task_off, M, (uint32_t)ilog2(plan.Lmax),
-                           plan.merged ? 1u : 0u, partials);
+        const dim3 grid((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS));
+        if (R)
+            hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, true>), grid, dim3(ACC_THREADS), 0, st, walk, (int64_t)0, (uint64_t)0,
+                               (const uint32_t*)nullptr, ss.offsets, ss.task_off, M, (uint32_t)R, (uint32_t)ilog2(plan.Lmax), 0u, partials);
+        else
+            hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, false>), grid, dim3(ACC_THREADS), 0, st, d_bases, shift, base_count, ss.sorted,
+                               ss.offsets, ss.task_off, M, 0u, (uint32_t)ilog2(plan.Lmax), plan.merged ? 1u : 0u, partials);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));

@@ -79,16 +79,22 @@ def test_witness_map_padded_domain_and_dense_rows(env, orc, g):
         assert mont_to_ints(h, cp.r) == pm.witness_map_from_matrices(cp, cs, z)
 
 
-@pytest.fixture(params=["per_window", "merged", "merged_c17", "merged_c20"])
+@pytest.fixture(params=["per_window", "merged", "merged_c17", "merged_c20", "per_window_affine2", "merged_affine3", "merged_c17_affine4",
+                        "merged_c20_affine1"])
 def msm_path(request, monkeypatch):
     """which bucket scheme g16_msm_* runs: per-window buckets (ad-hoc bases, the default of that entry point) or the
     proving-key scheme -- window tables + merged windows -- with the window size from the cost model or forced so that the
     bucket set is cut into 2 / 16 classes (the shape a 2^22 key uses) even at test sizes.  The library reads the
     variables at call time."""
-    if request.param != "per_window":
+    name = request.param
+    # "..._affineR": R levels of batched-affine pairwise additions in front of the XYZZ bucket pass (the default for keys of
+    # 2^20 points and more; forced here so that holes, tangents, cancellations and identity bases run through it at test sizes)
+    monkeypatch.setenv("G16_MSM_AFFINE_LEVELS", name[-1] if "_affine" in name else "0")
+    name = name.split("_affine")[0]
+    if name != "per_window":
         monkeypatch.setenv("G16_MSM_API_PRECOMP", "1")
-    if request.param.startswith("merged_c"):
-        monkeypatch.setenv("G16_MSM_PRECOMP_WINDOW", request.param[len("merged_c"):])
+    if name.startswith("merged_c"):
+        monkeypatch.setenv("G16_MSM_PRECOMP_WINDOW", name[len("merged_c"):])
     return request.param
 
 
@@ -194,8 +200,11 @@ def test_proof_valid_crs_2_16_trapdoor_and_pairing(env, orc, g):
 
 
 @pytest.mark.parametrize("scheme", [{"G16_MSM_PRECOMP": "0"}, {"G16_MSM_PRECOMP_WINDOW": "16"}, {"G16_MSM_PRECOMP_WINDOW": "17"},
-                                    {"G16_MSM_PRECOMP_WINDOW": "20"}, {"G16_PK_TABLE_BUDGET_MB": "2.0"}],
-                         ids=["plain_bases", "tables_c16", "tables_c17", "tables_c20", "tables_do_not_fit"])
+                                    {"G16_MSM_PRECOMP_WINDOW": "20"}, {"G16_PK_TABLE_BUDGET_MB": "2.0"},
+                                    {"G16_MSM_PRECOMP": "0", "G16_MSM_AFFINE_LEVELS": "2"}, {"G16_MSM_AFFINE_LEVELS": "3"},
+                                    {"G16_MSM_PRECOMP_WINDOW": "10", "G16_MSM_AFFINE_LEVELS": "4"}],
+                         ids=["plain_bases", "tables_c16", "tables_c17", "tables_c20", "tables_do_not_fit", "plain_bases_affine2", "tables_affine3",
+                              "tables_c10_affine4"])
 def test_proof_bucket_schemes(env, orc, g, scheme, monkeypatch):
     """g16_pk_load decides how the key is held (plain bases + per-window buckets, or window tables + merged windows at
     the window size of the cost model); every choice must give the oracle's proof, including the 16-class shape of a
