@@ -10,6 +10,7 @@
 #include "fp30.hpp"
 #include <chrono>
 #include <future>
+#include <thread>
 #include <new>
 #include <type_traits>
 
@@ -70,6 +71,8 @@ struct g16_ctx {
     hipEvent_t ev_z = nullptr, ev_h = nullptr, ev_wm = nullptr, ev_acc[5] = {}, ev_done[5] = {}, ev_msm_start[5] = {};
     void* pinned = nullptr;  // window sums land here (hipHostMalloc)
     size_t pinned_bytes = 0;
+    // g16_ctx_create_multi: a multi-device context owns one full context per device and no device state of its own
+    std::vector<g16_ctx*> subs;
 };
 
 // Error exits of the entry points that launch on several streams: kernels still in flight reference arena memory that the
@@ -93,6 +96,7 @@ struct g16_circuit {
     g16_ctx* ctx;
     void* dc;  // DeviceCircuit<C>*
     uint64_t domain_size;
+    std::vector<g16_circuit*> subs;   // multi-device context: the circuit replicated on every device (dc == nullptr)
 };
 
 template <class C>
@@ -115,6 +119,16 @@ struct g16_pk {
     int curve;
     g16_ctx* ctx;
     void* dp;  // DevicePk<C>*
+    std::vector<g16_pk*> subs;        // multi-device context: shard i of the key on device i (dp == nullptr)
+};
+
+struct g16_dwm {
+    int curve;
+    g16_ctx* ctx;
+    const g16_circuit* circuit;
+    void* dw;   // DistWm<C>*
+    int rank, world;
+    uint64_t local_size;
 };
 
 namespace {
@@ -314,8 +328,10 @@ struct Impl {
     template <class X>
     static X load_xyzz(const uint64_t* src) { X p; memcpy(&p, src, sizeof(X)); return p; }
 
+    // h_ext != nullptr: the witness map was computed elsewhere (the distributed map: this rank's block of h, h_ext_len
+    // coefficients in the order the key's h shard was gathered in) -- it is taken as is and the map below is skipped
     static int prove_partial(g16_ctx* ctx, const g16_pk* pkh, const g16_circuit* ckh, const uint64_t* z, uint64_t n_assign, int on_device,
-                             int skip_b_g1, g16_partial* out) {
+                             int skip_b_g1, g16_partial* out, const Fr* h_ext = nullptr, uint64_t h_ext_len = 0) {
         const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
         const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
         hipStream_t s1 = ctx->stream, s2 = ctx->stream2, s3 = ctx->stream3;
@@ -324,7 +340,8 @@ struct Impl {
         const uint64_t m = n_assign - 1, w = n_assign - nin;
         // the reference slices full_assignment[1..], [num_inputs..] (prover.rs:44-45) and msm_bigint
         // truncates to the shorter side; a shard must lie inside the scalar vector it indexes
-        if (pk->a_start + pk->a_count > m || pk->l_start + pk->l_count > w || pk->h_start + pk->h_count > n) return G16_ERR_BAD_LENGTH;
+        if (pk->a_start + pk->a_count > m || pk->l_start + pk->l_count > w || pk->h_start + pk->h_count > (h_ext ? h_ext_len : n))
+            return G16_ERR_BAD_LENGTH;
         if (pk->b_g1_start != pk->a_start || pk->b_g1_count != pk->a_count || pk->b_g2_start != pk->a_start ||
             pk->b_g2_count != pk->a_count)
             return G16_ERR_BAD_ARG;  // a / b_g1 / b_g2 must be sharded identically (they share one bucket sort)
@@ -340,10 +357,15 @@ struct Impl {
         // alone, on stream 1 (~6 ms at 2^22): underneath the bucket passes their long-lived waves starve it (60+ ms
         // measured) and everything queued behind it piles up at the end of the proof.
         Fr* d_h = nullptr;
-        G16_TRY(ctx->arena.alloc_n(n, &d_h));
         ScalarSort sort_h, sort_z, sort_l;
         G16_TRY(ctx->t_wm.start(s1));
-        G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1, ctx->t_ntt)));
+        if (h_ext) {
+            d_h = const_cast<Fr*>(h_ext);
+            ctx->t_ntt[0].used = ctx->t_ntt[1].used = false;
+        } else {
+            G16_TRY(ctx->arena.alloc_n(n, &d_h));
+            G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1, ctx->t_ntt)));
+        }
         G16_TRY(ctx->t_wm.stop(s1));
         G16_HIP_TRY(hipEventRecord(ctx->ev_wm, s1));
 
@@ -567,6 +589,25 @@ struct Impl {
         return G16_OK;
     }
 
+    static int dwm_stage_api(g16_ctx* ctx, const g16_circuit* ckh, const void* dwp, int stage, const uint64_t* z, uint64_t n_assign, int on_device,
+                             uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local) {
+        const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
+        const DistWm<C>* dw = static_cast<const DistWm<C>*>(dwp);
+        DrainOnError drain(ctx);
+        const Fr* d_z = nullptr;
+        if (stage == 0) {
+            if (!z || n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
+            ctx->arena.reset();
+            G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
+        }
+        Fr* w[3] = {reinterpret_cast<Fr*>(work[0]), reinterpret_cast<Fr*>(work[1]), reinterpret_cast<Fr*>(work[2])};
+        Fr* rv[3] = {reinterpret_cast<Fr*>(recv[0]), reinterpret_cast<Fr*>(recv[1]), reinterpret_cast<Fr*>(recv[2])};
+        G16_TRY((dwm_stage<C>(ck, dw, stage, d_z, w, rv, reinterpret_cast<Fr*>(h_local), ctx->stream)));
+        G16_HIP_TRY(hipStreamSynchronize(ctx->stream));   // the caller's exchange runs on its own stream
+        drain.dismiss();
+        return G16_OK;
+    }
+
     template <class F>
     static int msm_api(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine) {
         typedef Affine<F> A;
@@ -782,6 +823,30 @@ struct Impl {
         }                                                                     \
     } while (0)
 
+static void g16_dwm_free_impl(g16_dwm* d) {
+    (void)hipSetDevice(d->ctx->device);
+    if (d->curve == G16_BLS12_381) dwm_destroy<Bls12_381>(static_cast<DistWm<Bls12_381>*>(d->dw));
+    else dwm_destroy<Bn254>(static_cast<DistWm<Bn254>*>(d->dw));
+    d->dw = nullptr;
+}
+
+// run fn(i) for i < n on n host threads; first non-zero status wins
+template <class Fn>
+static int for_each_device(int n, Fn fn) {
+    std::vector<int> rc((size_t)n, G16_OK);
+    std::vector<std::thread> th;
+    try {
+        for (int i = 1; i < n; ++i) th.emplace_back([&, i]() { rc[(size_t)i] = fn(i); });
+    } catch (...) {
+        for (auto& t : th) t.join();
+        return G16_ERR_INTERNAL;
+    }
+    rc[0] = fn(0);
+    for (auto& t : th) t.join();
+    for (int v : rc) if (v) return v;
+    return G16_OK;
+}
+
 extern "C" {
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
@@ -826,8 +891,44 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
     return G16_OK;
 }
 
+// one context over several GPUs of the node, so that the reference-shaped call stays ONE call
+// (Groth16::prove, src/lib.rs:76-82): g16_pk_load cuts the key into n_dev contiguous shards (one per device),
+// g16_circuit_load replicates the matrices, g16_prove runs one host thread per device (g16_prove_partial on its shard) and
+// folds the n_dev partial records on the host.  The exchange needs no collective in this single-process form: a partial record
+// is 1 152 bytes that each device's thread already leaves in host memory.  (The process-per-GPU form, bench.py --gpus N,
+// exchanges the same records with one RCCL all-gather.)  Device ids may repeat (several shards on one GPU: tests).
+int g16_ctx_create_multi(int curve, const int* device_ids, int n_dev, g16_ctx** out) {
+    if (!out || !device_ids || n_dev < 1 || n_dev > 64 || (curve != G16_BLS12_381 && curve != G16_BN254)) return G16_ERR_BAD_ARG;
+    if (n_dev == 1) return g16_ctx_create(curve, device_ids[0], out);
+    g16_ctx* c = new (std::nothrow) g16_ctx();
+    if (!c) return G16_ERR_OOM;
+    c->curve = curve;
+    c->device = device_ids[0];
+    c->stream = c->stream2 = c->stream3 = nullptr;
+    memset(&c->tm, 0, sizeof(c->tm));
+    for (int i = 0; i < n_dev; ++i) {
+        g16_ctx* sub = nullptr;
+        const int rc = g16_ctx_create(curve, device_ids[i], &sub);
+        if (rc) {
+            for (g16_ctx* s : c->subs) g16_ctx_destroy(s);
+            delete c;
+            return rc;
+        }
+        c->subs.push_back(sub);
+    }
+    *out = c;
+    return G16_OK;
+}
+
+int g16_ctx_num_devices(const g16_ctx* ctx) { return ctx ? (ctx->subs.empty() ? 1 : (int)ctx->subs.size()) : 0; }
+
 void g16_ctx_destroy(g16_ctx* ctx) {
     if (!ctx) return;
+    if (!ctx->subs.empty()) {
+        for (g16_ctx* sub : ctx->subs) g16_ctx_destroy(sub);
+        delete ctx;
+        return;
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
@@ -848,16 +949,57 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     delete ctx;
 }
 
-void* g16_ctx_stream(g16_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+void* g16_ctx_stream(g16_ctx* ctx) { return ctx ? (void*)(ctx->subs.empty() ? ctx->stream : ctx->subs[0]->stream) : nullptr; }
 
 int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
     if (!ctx || !view || !out) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) {
+        // the WHOLE key, cut here: a / b_g1 / b_g2 identically, l at the matching places (l index j <-> a index j + num_inputs - 1,
+        // and num_inputs - 1 = m - w for a whole key) so that every shard keeps sharing one witness sort, h evenly
+        const int n = (int)ctx->subs.size();
+        if (view->a.start || view->b_g1.start || view->b_g2.start || view->h.start || view->l.start) return G16_ERR_BAD_ARG;
+        if (view->b_g1.count != view->a.count || view->b_g2.count != view->a.count || view->l.count > view->a.count) return G16_ERR_BAD_LENGTH;
+        if (view->flags & G16_PK_DEVICE_PTRS)
+            for (g16_ctx* sub : ctx->subs) if (sub->device != ctx->subs[0]->device) return G16_ERR_BAD_ARG;   // host pointers across devices
+        g16_pk* h = new (std::nothrow) g16_pk{ctx->curve, ctx, nullptr};
+        if (!h) return G16_ERR_OOM;
+        h->subs.assign((size_t)n, nullptr);
+        const uint64_t m = view->a.count, w = view->l.count, hl = view->h.count, skip = m - w;
+        const size_t g1b = (ctx->curve == G16_BLS12_381 ? 12 : 8), g2b = 2 * g1b;   // u64 limbs per G1 / G2 affine point
+        const int rc = for_each_device(n, [&](int i) -> int {
+            g16_pk_view v = *view;
+            const uint64_t a_lo = m * (uint64_t)i / n, a_hi = m * (uint64_t)(i + 1) / n;
+            const uint64_t l_lo = std::min(w, a_lo > skip ? a_lo - skip : 0), l_hi = std::min(w, a_hi > skip ? a_hi - skip : 0);
+            const uint64_t h_lo = hl * (uint64_t)i / n, h_hi = hl * (uint64_t)(i + 1) / n;
+            auto cut = [](const g16_query& q, uint64_t lo, uint64_t hi, size_t limbs) {
+                g16_query r;
+                r.points = q.points ? q.points + lo * limbs : nullptr;
+                r.count = hi - lo;
+                r.start = lo;
+                return r;
+            };
+            v.a = cut(view->a, a_lo, a_hi, g1b);
+            v.b_g1 = cut(view->b_g1, a_lo, a_hi, g1b);
+            v.b_g2 = cut(view->b_g2, a_lo, a_hi, g2b);
+            v.l = cut(view->l, l_lo, l_hi, g1b);
+            v.h = cut(view->h, h_lo, h_hi, g1b);
+            return g16_pk_load(ctx->subs[(size_t)i], &v, &h->subs[(size_t)i]);
+        });
+        if (rc) { g16_pk_free(h); return rc; }
+        *out = h;
+        return G16_OK;
+    }
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::pk_load(ctx, view, out));
 }
 
 void g16_pk_free(g16_pk* pk) {
     if (!pk) return;
+    if (!pk->ctx->subs.empty()) {
+        for (g16_pk* sub : pk->subs) g16_pk_free(sub);
+        delete pk;
+        return;
+    }
     (void)hipSetDevice(pk->ctx->device);
     if (pk->curve == G16_BLS12_381) Impl<Bls12_381>::pk_free(static_cast<DevicePk<Bls12_381>*>(pk->dp));
     else Impl<Bn254>::pk_free(static_cast<DevicePk<Bn254>*>(pk->dp));
@@ -867,12 +1009,30 @@ void g16_pk_free(g16_pk* pk) {
 int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints, uint64_t num_variables,
                      g16_circuit** out) {
     if (!ctx || !abc || !out) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) {
+        const int n = (int)ctx->subs.size();
+        g16_circuit* h = new (std::nothrow) g16_circuit{ctx->curve, ctx, nullptr, 0};
+        if (!h) return G16_ERR_OOM;
+        h->subs.assign((size_t)n, nullptr);
+        const int rc = for_each_device(n, [&](int i) -> int {
+            return g16_circuit_load(ctx->subs[(size_t)i], abc, num_inputs, num_constraints, num_variables, &h->subs[(size_t)i]);
+        });
+        if (rc) { g16_circuit_free(h); return rc; }
+        h->domain_size = h->subs[0]->domain_size;
+        *out = h;
+        return G16_OK;
+    }
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::circuit_load(ctx, abc, num_inputs, num_constraints, num_variables, out));
 }
 
 void g16_circuit_free(g16_circuit* c) {
     if (!c) return;
+    if (!c->ctx->subs.empty()) {
+        for (g16_circuit* sub : c->subs) g16_circuit_free(sub);
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->ctx->device);
     if (c->curve == G16_BLS12_381) Impl<Bls12_381>::circuit_free(static_cast<DeviceCircuit<Bls12_381>*>(c->dc));
     else Impl<Bn254>::circuit_free(static_cast<DeviceCircuit<Bn254>*>(c->dc));
@@ -885,6 +1045,7 @@ int g16_prove_partial(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit
                       int assignment_on_device, int skip_b_g1, g16_partial* out) {
     if (!ctx || !pk || !circuit || !full_assignment || !out) return G16_ERR_BAD_ARG;
     if (pk->curve != ctx->curve || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty() || pk->ctx != ctx || circuit->ctx != ctx) return G16_ERR_BAD_ARG;   // multi-device contexts: g16_prove
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, out));
 }
@@ -893,6 +1054,10 @@ int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts,
                        g16_proof* out) {
     if (!ctx || !pk || !parts || !r || !s || !out) return G16_ERR_BAD_ARG;
     if (pk->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) {   // every shard carries the same eight fixed points
+        if (pk->subs.empty()) return G16_ERR_BAD_ARG;
+        return g16_prove_finalize(ctx->subs[0], pk->subs[0], parts, n_parts, r, s, out);
+    }
     G16_DISPATCH(ctx->curve, I::prove_finalize(ctx, pk, parts, n_parts, r, s, out));
 }
 
@@ -908,9 +1073,83 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
     g16_partial part;
     const uint64_t zero[4] = {0, 0, 0, 0};
     const int skip_b_g1 = memcmp(r, zero, 32) == 0;  // r == 0 skips B in G1 (prover.rs:98)
+    if (ctx && !ctx->subs.empty()) {
+        if (!pk || !circuit || !full_assignment || pk->ctx != ctx || circuit->ctx != ctx) return G16_ERR_BAD_ARG;
+        const int n = (int)ctx->subs.size();
+        if (assignment_on_device)   // a device pointer is valid on one GPU only
+            for (g16_ctx* sub : ctx->subs) if (sub->device != ctx->subs[0]->device) return G16_ERR_BAD_ARG;
+        const double t0 = now_ms();
+        std::vector<g16_partial> parts((size_t)n);
+        int rc = for_each_device(n, [&](int i) -> int {
+            return g16_prove_partial(ctx->subs[(size_t)i], pk->subs[(size_t)i], circuit->subs[(size_t)i], full_assignment, n_assign,
+                                     assignment_on_device, skip_b_g1, &parts[(size_t)i]);
+        });
+        if (rc) return rc;
+        rc = g16_prove_finalize(ctx->subs[0], pk->subs[0], parts.data(), n, r, s, out);
+        // timings: the slowest device's phases (the proof waits for it), wall time of the whole call
+        int slow = 0;
+        for (int i = 1; i < n; ++i) if (ctx->subs[(size_t)i]->tm.total_ms > ctx->subs[(size_t)slow]->tm.total_ms) slow = i;
+        ctx->tm = ctx->subs[(size_t)slow]->tm;
+        ctx->tm.finish_ms = ctx->subs[0]->tm.finish_ms;
+        ctx->tm.total_ms = now_ms() - t0;
+        return rc;
+    }
     int rc = g16_prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, &part);
     if (rc) return rc;
     return g16_prove_finalize(ctx, pk, &part, 1, r, s, out);
+}
+
+int g16_prove_partial_h(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
+                        int assignment_on_device, const uint64_t* h_dev, uint64_t h_len, int skip_b_g1, g16_partial* out) {
+    if (!ctx || !pk || !circuit || !full_assignment || !h_dev || !out) return G16_ERR_BAD_ARG;
+    if (pk->curve != ctx->curve || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty() || pk->ctx != ctx || circuit->ctx != ctx) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, out,
+                                              reinterpret_cast<const typename I::Fr*>(h_dev), h_len));
+}
+
+int g16_dwm_create(g16_ctx* ctx, const g16_circuit* circuit, int rank, int world, g16_dwm** out) {
+    if (!ctx || !circuit || !out || circuit->curve != ctx->curve || circuit->ctx != ctx || !ctx->subs.empty()) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    void* dw = nullptr;
+    int rc;
+    try {
+        if (ctx->curve == G16_BLS12_381) {
+            DistWm<Bls12_381>* d = nullptr;
+            rc = dwm_create<Bls12_381>(static_cast<const DeviceCircuit<Bls12_381>*>(circuit->dc), rank, world, ctx->stream, &d);
+            dw = d;
+        } else {
+            DistWm<Bn254>* d = nullptr;
+            rc = dwm_create<Bn254>(static_cast<const DeviceCircuit<Bn254>*>(circuit->dc), rank, world, ctx->stream, &d);
+            dw = d;
+        }
+    } catch (...) {
+        return G16_ERR_OOM;
+    }
+    if (rc) return rc;
+    g16_dwm* h = new (std::nothrow) g16_dwm{ctx->curve, ctx, circuit, dw, rank, world, circuit->domain_size / (uint64_t)world};
+    if (!h) { g16_dwm tmp{ctx->curve, ctx, circuit, dw, rank, world, 0}; g16_dwm_free_impl(&tmp); return G16_ERR_OOM; }
+    *out = h;
+    return G16_OK;
+}
+
+void g16_dwm_free(g16_dwm* d) {
+    if (!d) return;
+    g16_dwm_free_impl(d);
+    delete d;
+}
+
+uint64_t g16_dwm_local_size(const g16_dwm* d) { return d ? d->local_size : 0; }
+
+int g16_dwm_stage(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assignment, uint64_t n_assign, int assignment_on_device,
+                  uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local) {
+    if (!ctx || !d || d->ctx != ctx || !work || !recv || stage < 0 || stage > 3) return G16_ERR_BAD_ARG;
+    if ((stage == 0 && (!work[0] || !work[1] || !work[2])) || (stage == 1 && (!work[0] || !work[1] || !work[2] || !recv[0] || !recv[1] || !recv[2])) ||
+        (stage == 2 && (!work[0] || !recv[0] || !recv[1] || !recv[2])) || (stage == 3 && (!recv[0] || !h_local)))
+        return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::dwm_stage_api(ctx, d->circuit, d->dw, stage, full_assignment, n_assign, assignment_on_device, work, recv, h_local));
 }
 
 int g16_get_timings(g16_ctx* ctx, g16_timings* out) {
@@ -921,31 +1160,36 @@ int g16_get_timings(g16_ctx* ctx, g16_timings* out) {
 
 int g16_witness_map(g16_ctx* ctx, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign, int on_device,
                     uint64_t* h_out) {
-    if (!ctx || !circuit || !full_assignment || !h_out || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    if (!ctx || !circuit || !full_assignment || !h_out || circuit->curve != ctx->curve || circuit->ctx != ctx) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) return g16_witness_map(ctx->subs[0], circuit->subs[0], full_assignment, n_assign, on_device, h_out);
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::witness_map_api(ctx, circuit, full_assignment, n_assign, on_device, h_out));
 }
 
 int g16_msm_g1(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine) {
     if (!ctx || !out_affine || (n && (!bases || !scalars))) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) return g16_msm_g1(ctx->subs[0], bases, scalars, n, out_affine);
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::template msm_api<typename I::Fq>(ctx, bases, scalars, n, out_affine));
 }
 
 int g16_msm_g2(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine) {
     if (!ctx || !out_affine || (n && (!bases || !scalars))) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) return g16_msm_g2(ctx->subs[0], bases, scalars, n, out_affine);
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::template msm_api<typename I::Fq2>(ctx, bases, scalars, n, out_affine));
 }
 
 int g16_ntt(g16_ctx* ctx, uint64_t* data, int log_n, int inverse, int coset) {
     if (!ctx || !data) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) return g16_ntt(ctx->subs[0], data, log_n, inverse, coset);
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::ntt_api(ctx, data, log_n, inverse, coset));
 }
 
 int g16_synth_bases(g16_ctx* ctx, int g2, uint64_t seed, uint64_t first, uint64_t n, uint64_t* out_dev) {
     if (!ctx || (n && !out_dev)) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) return g16_synth_bases(ctx->subs[0], g2, seed, first, n, out_dev);
     G16_HIP_TRY(hipSetDevice(ctx->device));
     int rc;
     if (ctx->curve == G16_BLS12_381) rc = synth_bases_device<Bls12_381>(g2, seed, first, n, out_dev, ctx->stream);
@@ -977,6 +1221,8 @@ int g16_generate_parameters(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t nu
                             const g16_toxic_waste* tw, const uint64_t* g1_generator, const uint64_t* g2_generator, const g16_params_view* out) {
     if (!ctx || !abc || !tw || !g1_generator || !g2_generator || !out) return G16_ERR_BAD_ARG;
     if (!out->alpha_g1 || !out->beta_g1 || !out->delta_g1 || !out->beta_g2 || !out->delta_g2 || !out->gamma_g2) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty())
+        return g16_generate_parameters(ctx->subs[0], abc, num_inputs, num_constraints, num_variables, tw, g1_generator, g2_generator, out);
     G16_HIP_TRY(hipSetDevice(ctx->device));
     try {
         if (ctx->curve == G16_BLS12_381)

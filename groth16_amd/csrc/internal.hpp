@@ -101,6 +101,9 @@ template <class C> int ntt_dif_dit(const Domain<C>* d, typename C::Fr* data, boo
 template <class C> int bitrev_scale(const Domain<C>* d, typename C::Fr* out, const typename C::Fr* in, const typename C::Fr* table,
                                     const typename C::Fr* cst, hipStream_t st);
 template <class C> int scale_by_table(typename C::Fr* data, const typename C::Fr* table, size_t n, hipStream_t st);
+// out[i] = scale * base^i for i < n, in the w*R' form of the 30-bit kernels (r30_form) or in the standard Montgomery form
+template <class C> int gen_power_table(typename C::Fr* out, size_t n, const typename C::Fr& base, const typename C::Fr& scale, bool r30_form,
+                                       hipStream_t st);
 
 // ---- R1CS on device + witness map (witness_map.hip) -------------------------------------------
 template <class C>
@@ -116,6 +119,33 @@ struct DeviceCircuit {
 // d_z: full assignment on device; d_h: n Fr out (natural order).  Scratch comes from the arena.
 template <class C> int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, typename C::Fr* d_h, Arena& arena,
                                           hipStream_t st, EventTimer* ntt_timers = nullptr);
+
+// ---- distributed witness map (witness_map.hip): the same h over N ranks, one all-to-all per transform --------------------
+// n = N * M, blk = M / N (needs N^2 | n, N a power of two <= 16).  Two distributions of an n-vector over the ranks:
+//   residue:  rank r holds x[r + N * i2],  i2 < M          block:  rank r holds x[(r * blk + j) + M * k1],  j < blk, k1 < N
+// An n-point transform is a local M-point transform, a twiddle, ONE exchange (chunk p of M / N elements goes to rank p) and a
+// local N-point transform ("4-step"); residue -> block and block -> residue alternate, so ifft, coset fft, pointwise, coset ifft
+// need no redistribution in between and every rank ends with the h coefficients of its block indices -- the cut h_query then
+// has to be sharded by.  Modelled and index-checked in oracle/pymodel.py::distributed_witness_map.
+template <class C>
+struct DistWm {
+    typedef typename C::Fr Fr;
+    int rank = 0, world = 1, log_world = 0;
+    size_t M = 0, blk = 0;
+    Domain<C>* dom_m = nullptr;   // the M-point domain (root w_n^N)
+    Fr* tw1 = nullptr;            // [M]       w_n^(-r k2)                        (w*R' form)
+    Fr* sc_mid = nullptr;         // [N][blk]  n^-1 g^((r blk + j) + M k1)        (standard form, like the three below)
+    Fr* tw2 = nullptr;            // [N][blk]  w_n^((r blk + j) ka)
+    Fr* sc_out = nullptr;         // [N][blk]  n^-1 g^-((r blk + j) + M k1)
+    Fr wn_fwd[8], wn_inv[8];      // w_N^k, w_N^-k for k < N / 2 (w_N = w_n^M)
+    Fr zinv;
+};
+template <class C> int dwm_create(const DeviceCircuit<C>* ck, int rank, int world, hipStream_t st, DistWm<C>** out);
+template <class C> void dwm_destroy(DistWm<C>* d);
+// stage 0: z -> work[0..2] (a, b, c; M Fr each);  exchange work -> recv;   stage 1: recv[0..2] -> work[0..2];  exchange;
+// stage 2: recv[0..2] -> work[0] (the quotient);   exchange work[0] -> recv[0];   stage 3: recv[0] -> h_local (M Fr)
+template <class C> int dwm_stage(const DeviceCircuit<C>* ck, const DistWm<C>* dw, int stage, const typename C::Fr* d_z,
+                                 typename C::Fr* const work[3], typename C::Fr* const recv[3], typename C::Fr* h_local, hipStream_t st);
 
 // ---- MSM (msm.hip) ----------------------------------------------------------------------------
 struct MsmPlan {

@@ -384,6 +384,20 @@ static int gen_powers30(Fr* out, size_t n, const Fr& base, const Fr& scale, int 
     return G16_OK;
 }
 
+// out[i] = scale * base^i, i < n: in the w*R' form the 30-bit kernels multiply by (r30_form) or in the standard Montgomery form
+template <class C>
+int gen_power_table(typename C::Fr* out, size_t n, const typename C::Fr& base, const typename C::Fr& scale, bool r30_form, hipStream_t st) {
+    typedef typename C::Fr Fr;
+    if (r30_form) return gen_powers30<Fr>(out, n, base, scale, 0, st);
+    if (n == 0) return G16_OK;
+    PowTable<Fr> tab;
+    Fr p = base;
+    for (int j = 0; j < 32; ++j) { tab.p[j] = p; p = p.sqr(); }
+    hipLaunchKernelGGL((gen_powers_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, tab, scale, 0);
+    G16_LAUNCH_CHECK();
+    return G16_OK;
+}
+
 template <class C>
 int domain_create(int log_n, hipStream_t st, Domain<C>** out) {
     typedef typename C::Fr Fr;
@@ -438,7 +452,8 @@ void domain_destroy(Domain<C>* d) {
     template int ntt_dif_dit<C>(const Domain<C>*, typename C::Fr*, bool, const typename C::Fr*, hipStream_t);      \
     template int bitrev_scale<C>(const Domain<C>*, typename C::Fr*, const typename C::Fr*, const typename C::Fr*,  \
                                  const typename C::Fr*, hipStream_t);                                              \
-    template int scale_by_table<C>(typename C::Fr*, const typename C::Fr*, size_t, hipStream_t);
+    template int scale_by_table<C>(typename C::Fr*, const typename C::Fr*, size_t, hipStream_t);                   \
+    template int gen_power_table<C>(typename C::Fr*, size_t, const typename C::Fr&, const typename C::Fr&, bool, hipStream_t);
 
 G16_INSTANTIATE_NTT(Bls12_381)
 G16_INSTANTIATE_NTT(Bn254)

@@ -100,11 +100,18 @@ def shard_ranges(m: int, w: int, h_len: int, num_inputs: int, idx: int, cnt: int
 
 
 class _Ctx:
-    def __init__(self, curve: str, device: int):
+    def __init__(self, curve: str, device):
+        """device: one HIP device id, or a sequence of them (g16_ctx_create_multi: the key is sharded over the devices inside
+        the library and one g16_prove call uses all of them)"""
         self.lib = lib()
         self.curve = curve
         self.handle = C.c_void_p()
-        self.lib.check(self.lib.c.g16_ctx_create(CURVE_ID[curve], device, C.byref(self.handle)))
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*[int(d) for d in device])
+            self.lib.check(self.lib.c.g16_ctx_create_multi(CURVE_ID[curve], ids, len(device), C.byref(self.handle)))
+        else:
+            self.lib.check(self.lib.c.g16_ctx_create(CURVE_ID[curve], device, C.byref(self.handle)))
+        self.num_devices = int(self.lib.c.g16_ctx_num_devices(self.handle))
 
     def close(self):
         if self.handle:
@@ -180,12 +187,13 @@ class LibsnarkReduction:
 
 
 class Groth16:
-    """``Groth16::<E, LibsnarkReduction>`` prover methods for E in {Bls12_381, Bn254} on one MI355X.
+    """``Groth16::<E, LibsnarkReduction>`` prover methods for E in {Bls12_381, Bn254} on one MI355X (``device=0``) or on
+    several GPUs of the node behind the same calls (``device=[0, 1, ...]``: the library shards the key and folds the partial sums).
 
     Device-resident copies of proving keys and constraint matrices are cached per object
     (they are per-circuit constants, like ``&pk`` in the reference)."""
 
-    def __init__(self, curve: str = "bls12_381", device: int = 0):
+    def __init__(self, curve: str = "bls12_381", device=0):
         if curve not in CURVE_ID:
             raise ValueError(f"unsupported curve {curve}")
         self.curve = curve
@@ -207,6 +215,12 @@ class Groth16:
         if id(m) not in self._cks:
             self._cks[id(m)] = (m, _DeviceCircuit(self._ctx, m))
         return self._cks[id(m)][1]
+
+    def evict_pk(self, pk: ProvingKey, shard=(0, 1)):
+        """drop the device-resident copy of one key shard (its window tables are 13x the shard)"""
+        ent = self._pks.pop((id(pk), shard), None)
+        if ent is not None:
+            ent[1].close()
 
     def evict(self):
         """drop every cached device-resident key / circuit (frees their HBM)"""

@@ -25,7 +25,8 @@
  *   CSR matrix     : row_ptr u64[num_constraints+1], col u32[nnz], val Fr[nnz]; built from
  *                    ConstraintMatrices' Vec<Vec<(F, usize)>> rows
  * All functions return 0 on success or a g16_status; they never throw or unwind.
- * A g16_ctx is bound to one HIP device and is thread-compatible (one call in flight per ctx).
+ * A g16_ctx is bound to one HIP device (g16_ctx_create) or to several (g16_ctx_create_multi) and is thread-compatible
+ * (one call in flight per ctx).
  */
 #ifndef G16_MI355X_H
 #define G16_MI355X_H
@@ -128,6 +129,15 @@ typedef struct {
 } g16_timings;
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out);
+/* One context over n_dev GPUs of the node, so that the reference's single call -- Groth16::prove, src/lib.rs:76-82
+ * -> create_proof_with_reduction, src/prover.rs:173-217 -- stays a single g16_prove: g16_pk_load (given the WHOLE key: every
+ * query.start == 0, host pointers) cuts the five MSM base arrays into n_dev contiguous shards, one per device;
+ * g16_circuit_load replicates the matrices; g16_prove (host full_assignment) runs one host thread per device and folds the
+ * n_dev partial records on the host.  g16_prove_partial is the per-device form and is refused on such a context;
+ * g16_prove_finalize and the unit-level entry points run on the first device.  device_ids may repeat.  n_dev == 1 is
+ * g16_ctx_create. */
+int g16_ctx_create_multi(int curve, const int* device_ids, int n_dev, g16_ctx** out);
+int g16_ctx_num_devices(const g16_ctx* ctx);
 void g16_ctx_destroy(g16_ctx* ctx);
 /* HIP stream the ctx launches on (hipStream_t); lets callers bracket work with their own events */
 void* g16_ctx_stream(g16_ctx* ctx);
@@ -151,6 +161,26 @@ int g16_prove_partial(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit
                       uint64_t n_assign, int assignment_on_device, int skip_b_g1, g16_partial* out);
 int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts, int n_parts, const uint64_t r[4],
                        const uint64_t s[4], g16_proof* out);
+
+/* ---- distributed witness map (the Amdahl term of the sharded proof) ----
+ * h = witness_map_from_matrices (src/r1cs_to_qap.rs:172-235) over `world` ranks (a power of two <= 16 with world^2 | domain_size),
+ * every n-point transform as a local (n / world)-point transform, a twiddle, ONE all-to-all and a local world-point transform.
+ * Rank r ends with the h coefficients of its BLOCK indices  (r * blk + j) + M * k1,  j < blk = M / world, k1 < world, M = n / world,
+ * in the order [k1][j] -- which is how that rank's h_query shard has to be gathered (g16_pk_view.h = those bases, start 0).
+ * The caller owns the buffers (device memory, M = g16_dwm_local_size() Fr each) and the exchange: after stages 0, 1 (three
+ * arrays: a, b, c) and 2 (one array), chunk p (M / world elements) of each work array goes to rank p, which stores the chunk
+ * from rank q at position q of the matching recv array -- an all-to-all (RCCL over xGMI: torch.distributed.all_to_all_single).
+ *   stage 0: full_assignment -> work[0..2]     stage 1: recv[0..2] -> work[0..2]     stage 2: recv[0..2] -> work[0]
+ *   stage 3: recv[0] -> h_local.               Each call returns with its device work finished. */
+typedef struct g16_dwm g16_dwm;
+int g16_dwm_create(g16_ctx* ctx, const g16_circuit* circuit, int rank, int world, g16_dwm** out);
+void g16_dwm_free(g16_dwm* d);
+uint64_t g16_dwm_local_size(const g16_dwm* d);
+int g16_dwm_stage(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assignment, uint64_t n_assign, int assignment_on_device,
+                  uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local);
+/* g16_prove_partial with h supplied by the caller (device memory, h_len Fr; the key's h shard indexes it from h.start) */
+int g16_prove_partial_h(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
+                        int assignment_on_device, const uint64_t* h_dev, uint64_t h_len, int skip_b_g1, g16_partial* out);
 
 /* the same fold + glue without a GPU context: only the eight fixed points of `fixed` are read.  Lets a host
  * process that merely aggregates shard records (or the CPU multi-rank tests) finish a proof. */

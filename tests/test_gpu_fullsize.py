@@ -174,3 +174,30 @@ def test_reference_bench_circuit_shape_2_20(g, orc, curve):
     assert (proof.flat() == orc.trapdoor_proof(ck, ex, h_orc, r, s)).all()
     o_proof, _ = orc.prove(flat_pk(curve, pk), ck, r, s)
     assert (o_proof == proof.flat()).all()
+
+
+def test_sharded_2_24_three_shards_trapdoor(g, orc):
+    """BASELINE.json configs[4] (2^24 constraints, BLS12-381, MSM bases sharded) at reduced cost on ONE GPU: the key is cut
+    into three shards, each shard's partial sums are computed on their own (tables loaded, proved, evicted), the records are
+    folded by g16_prove_finalize, and the proof must equal the trapdoor closed form -- the five sums of prover.rs:66,74,92,
+    105,113 are the same whatever the cut.  Exercises what exists only at this size: 2^24-point domains (four-sweep NTTs),
+    entry tags point | window << 26 near their limits, multi-gigabyte arenas."""
+    curve, k = "bls12_381", 24
+    ck = orc.syn_circuit(curve, k, 3)
+    toxic = orc.rand_fr(curve, 924, 5)
+    gens = orc.setup(orc.syn_circuit(curve, 2, 1), 3)[1]
+    r, s = orc.rand_fr(curve, 81, 1)[0], orc.rand_fr(curve, 82, 1)[0]
+    with g.Groth16(curve, 0) as prover:
+        mats = mats_of(g, ck)
+        pk = prover.generate_parameters_with_qap(mats, toxic[0], toxic[1], toxic[2], toxic[3], gens["g1gen"], gens["g2gen"], toxic[4])
+        parts = []
+        for i in range(3):
+            parts.append(prover.prove_partial(pk, mats, ck.z, (i, 3)))
+            if i < 2:
+                prover.evict_pk(pk, (i, 3))
+        proof = prover.prove_finalize(pk, ck.num_inputs, parts, r, s, (2, 3))
+        h_gpu = prover.witness_map_from_matrices(mats, ck.num_inputs, ck.num_constraints, ck.z)
+    h_orc = orc.witness_map(ck)
+    assert (h_gpu == h_orc).all()
+    ex = trapdoor_extras(g, curve, ck, toxic, gens["g1gen"], gens["g2gen"])
+    assert (proof.flat() == orc.trapdoor_proof(ck, ex, h_orc, r, s)).all()

@@ -301,6 +301,30 @@ def test_sharded_proof_equals_single(env, orc, g):
     assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_multi_device_context_single_call(orc, g, curve):
+    """g16_ctx_create_multi: ONE g16_prove over a context of several devices -- here the one visible GPU
+    three times -- shards the key inside the library, runs a host thread per device and folds the partial records; the
+    proof equals the oracle's, r = 0 included (prover.rs:98-108), and the per-device form is refused on such a context"""
+    ck = orc.syn_circuit(curve, 11, 6)
+    pk, _ = orc.setup(ck, 4)
+    gm, gp = mats_of(g, ck), pk_of(g, pk)
+    with g.Groth16(curve, [0, 0, 0]) as prover:
+        assert prover._ctx.num_devices == 3
+        for r, s in ((orc.rand_fr(curve, 91, 1)[0], orc.rand_fr(curve, 92, 1)[0]), (np.zeros(4, dtype=np.uint64), orc.rand_fr(curve, 93, 1)[0])):
+            proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
+            assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+        assert prover.timings()["total_ms"] > 0
+        assert (prover.witness_map_from_matrices(gm, ck.num_inputs, ck.num_constraints, ck.z) == orc.witness_map(ck)).all()
+        with pytest.raises(g.G16Error):
+            prover.prove_partial(gp, gm, ck.z, (0, 1))
+    with g.Groth16(curve, [0]) as prover:      # n_dev == 1 is the plain context
+        assert prover._ctx.num_devices == 1
+        r, s = orc.rand_fr(curve, 94, 1)[0], orc.rand_fr(curve, 95, 1)[0]
+        proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
+        assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+
+
 def test_error_paths(env, orc, g):
     curve, prover = env
     ck = orc.syn_circuit(curve, 4, 3)
