@@ -162,6 +162,21 @@ struct Fp30 {
         return wide_redc(T);
     }
     G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
+    // a*b - c*d with ONE Montgomery reduction (the double-width sums share it): 3 NL^2 multiply-adds instead of 4 NL^2.
+    // Requires d < 2p and a*b + 2p*c < ~400 p^2; output < 1.2p for the bounds the group formulas feed it.
+    G16_HD static Fp30 mul_sub(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) {
+#if defined(G16_FP30_OUTLINE) || defined(G16_NO_MUL_SUB)
+        return a.mul(b).template sub<2>(c.mul(d));
+#else
+        uint64_t T[2 * NL];
+        const Fp30 nd = d.neg2();
+        wide_mul(T, a, b);
+        wide_normalize(T);
+        wide_mul_add(T, c, nd);
+        wide_normalize(T);
+        return wide_redc(T);
+#endif
+    }
     G16_HD Fp30 sqr() const {
 #if defined(G16_FP30_OUTLINE) || defined(G16_FP30_NO_SQR)
         return mul(*this);
@@ -365,6 +380,7 @@ struct Fp2x30 {
     G16_HD Std to_std() const { return {c0.to_std(), c1.to_std()}; }
     G16_HD Std to_packed() const { return {c0.to_packed(), c1.to_packed()}; }
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
+    G16_HD static Fp2x30 mul_sub(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return a.mul(b).template sub<KM>(c.mul(d)); }
     G16_HD Fp2x30 settle() const { return *this; }
     G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     typedef Fp2x30 Raw;
@@ -424,6 +440,7 @@ struct Fp2k30 {
     G16_HD Std to_packed() const { return {c0.to_packed(), c1.to_packed()}; }
     // product outputs < 6p -> subtract them with K = 8 (16 when doubled); x, y are settled below 2p
     static constexpr int KM = 8, K2M = 16, KX = 2, KY = 2;
+    G16_HD static Fp2k30 mul_sub(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return a.mul(b).template sub<KM>(c.mul(d)); }
     G16_HD Fp2k30 settle() const { return {c0.weak_reduce32(), c1.weak_reduce32()}; }
     G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     typedef Fp2x30<P> Raw;
@@ -498,6 +515,36 @@ struct Fp2p30 {
         const B x = sel(hi, o.dbl(), m.add(o));                      // lane0: a0+a1      lane1: 2 a0
         const B y = sel(hi, m, m.template sub<16>(o));               // lane0: a0-a1+16p  lane1: a1
         return x.mul_impl(y);
+    }
+    // this lane's component of a*b - c*d (d's components < 2p): four limb-product sweeps, ONE reduction
+    //     lane 0:  a0 b0 + a1 (16p - b1) + c0 (2p - d0) + c1 d1        lane 1:  a0 b1 + a1 b0 + c0 (2p - d1) + c1 (2p - d0)
+    G16_HD static B pair_mul_sub(bool hi, const B& ma, const B& oa, const B& mb, const B& ob, const B& mc, const B& oc, const B& md,
+                                 const B& od) {
+        const B a0 = sel(hi, oa, ma), a1 = sel(hi, ma, oa);
+        const B c0 = sel(hi, oc, mc), c1 = sel(hi, mc, oc);
+        const B y2 = sel(hi, ob, ob.neg16());         // lane0: 16p-b1  lane1: b0
+        const B z1 = md.neg2();                       // lane0: 2p-d0   lane1: 2p-d1
+        const B z2 = sel(hi, od.neg2(), od);          // lane0: d1      lane1: 2p-d0
+        uint64_t T[2 * B::NL];
+        B::wide_mul(T, a0, mb);
+        B::wide_normalize(T);
+        B::wide_mul_add(T, a1, y2);
+        B::wide_normalize(T);
+        B::wide_mul_add(T, c0, z1);
+        B::wide_normalize(T);
+        B::wide_mul_add(T, c1, z2);
+        B::wide_normalize(T);
+        return B::wide_redc(T);
+    }
+    // Measured (profiles/r02_ab_mul_sub.txt, 2^22, same box): the fused form is 4.7 % FASTER for G1 (Fp30::mul_sub) but 5 %
+    // SLOWER here (27.9 -> 29.3 ms per G2 pass): eight operand sets + the column array exceed the 256 VGPRs the two-waves-per-SIMD
+    // bucket kernel has.  The lane-pair field therefore keeps two products (G16_PAIR_MUL_SUB opts in).
+    G16_HD static Fp2p30 mul_sub(const Fp2p30& a, const Fp2p30& b, const Fp2p30& c, const Fp2p30& d) {
+#ifdef G16_PAIR_MUL_SUB
+        return {pair_mul_sub(lane_hi(), a.c, swap(a.c), b.c, swap(b.c), c.c, swap(c.c), d.c, swap(d.c))};
+#else
+        return a.mul(b).template sub<2>(c.mul(d));
+#endif
     }
     G16_HD static Fp2p30 zero() { return {B::zero()}; }
     G16_HD static Fp2p30 one() { return {lane_hi() ? B::zero() : B::one()}; }
@@ -587,7 +634,7 @@ struct Acc30 {
         const F X2 = px.sqr();
         const F M = X2.dbl().add(X2);             // < 3 * (square bound)
         const F X3 = M.sqr().template sub<F::K2M>(S.dbl()).settle();
-        const F Y3 = M.mul(S.template sub<F::KX>(X3)).template sub<F::KM>(W.mul(py)).settle();
+        const F Y3 = F::mul_sub(M, S.template sub<F::KX>(X3), py, W).settle();
         x = X3; y = Y3; zz = V; zzz = W;
         inf = false;
     }
@@ -613,7 +660,7 @@ struct Acc30 {
         const F PPP = Pd.mul(PP);
         const F Q = x.mul(PP);
         const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
-        const F Y3 = R.mul(Q.template sub<F::KX>(X3)).template sub<F::KM>(y.mul(PPP)).settle();
+        const F Y3 = F::mul_sub(R, Q.template sub<F::KX>(X3), y, PPP).settle();
         x = X3;
         y = Y3;
         zz = zz.mul(PP);
@@ -630,7 +677,7 @@ struct Acc30 {
         const F X2 = x.sqr();
         const F M = X2.dbl().add(X2);
         const F X3 = M.sqr().template sub<F::K2M>(S.dbl()).settle();
-        const F Y3 = M.mul(S.template sub<F::KX>(X3)).template sub<F::KM>(W.mul(y)).settle();
+        const F Y3 = F::mul_sub(M, S.template sub<F::KX>(X3), y, W).settle();
         x = X3; y = Y3;
         zz = V.mul(zz);
         zzz = W.mul(zzz);
@@ -656,7 +703,7 @@ struct Acc30 {
         const F PPP = Pd.mul(PP);
         const F Q = U1.mul(PP);
         const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
-        const F Y3 = R.mul(Q.template sub<F::KX>(X3)).template sub<F::KM>(S1.mul(PPP)).settle();
+        const F Y3 = F::mul_sub(R, Q.template sub<F::KX>(X3), S1, PPP).settle();
         x = X3;
         y = Y3;
         zz = zz.mul(o.zz).mul(PP);

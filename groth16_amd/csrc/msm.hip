@@ -666,7 +666,12 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
     plan->affine_levels = 0;
     {
         const uint64_t mean_load = all_entries / plan->buckets();
-        int R = (plan->merged && mean_load >= 24 && all_entries >= (8ull << 20)) ? 3 : 0;
+        // Measured (profiles/r02_affine_v1_kernel_stats.csv, 2^22, BLS12-381): the levels LOSE on this GPU -- level 0 gathers
+        // every operand twice and spills a prefix product per pair (~750 B of mostly random HBM traffic per addition against
+        // ~137 B for the XYZZ walk), 8.0 ms for the 27 M additions that cost the XYZZ pass 6.3 ms -- so the default is 0 and the
+        // path stays as a measured, tested experiment.
+        (void)mean_load;
+        int R = 0;
         if (const char* e = getenv("G16_MSM_AFFINE_LEVELS")) {   // 0 disables, 1..4 forces (tests run it at tiny sizes)
             const int v = atoi(e);
             if (v >= 0 && v <= 4) R = v;
