@@ -10,8 +10,10 @@ resident in HBM when the timed region starts -- the scope of
 Groth16::create_proof_with_reduction_and_matrices (/root/reference/src/prover.rs:26-51).
 
 N > 1 (one process per GPU, launched by torch.distributed.run): the MSM base arrays are sharded over
-the ranks (strong scaling: the SAME proof), every rank computes its partial sums, ONE all-gather of the
-1.2 KB partial records over RCCL combines them and every rank finishes the proof.
+the ranks (strong scaling: the SAME proof), the witness map is distributed too (g16_dwm_*: every n-point transform as a
+local n/N-point transform, a twiddle, ONE all-to-all over RCCL and a local N-point transform; h stays in the block
+distribution its h_query shard is gathered in), every rank computes its partial sums, ONE all-gather of the 1.2 KB
+partial records over RCCL combines them and every rank finishes the proof.
 
 Prints one JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      dominant kernel (the G1 bucket-accumulation pass) against the 8 TB/s HBM roofline
@@ -35,7 +37,7 @@ import torch  # noqa: E402
 import groth16_amd as g  # noqa: E402
 from groth16_amd.binding import (CURVE_ID, FQ_LIMBS, CsrViewC, ParamsViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC, ToxicWasteC,  # noqa: E402
                                  ptr32, ptr64)
-from groth16_amd.groth16 import _MODULUS_R  # noqa: E402
+from groth16_amd.groth16 import _MODULUS_R, DistributedWitnessMap, dist_h_indices  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -48,8 +50,10 @@ class DeviceProver:
     """SYN(k) circuit + proving-key shard, everything resident on one GPU.  key = "valid": the CRS of the circuit, generated
     on the GPU from seeded toxic waste; "synthetic": distinct non-identity points (any points give the same prover work)."""
 
-    def __init__(self, curve, k, seed, rank, world, device, key="valid"):
+    def __init__(self, curve, k, seed, rank, world, device, key="valid", dist_wm=False):
+        """dist_wm: this rank runs its part of the distributed witness map and holds the h_query shard in block order"""
         self.curve, self.k, self.rank, self.world, self.key = curve, k, rank, world, key
+        self.dwm, self.dwm_ms = None, 0.0
         self.lib = g.lib()
         c = self.lib.c
         L = FQ_LIMBS[curve]
@@ -77,8 +81,13 @@ class DeviceProver:
         l_lo = min(w, max(0, a_lo - (self.nin - 1)))
         l_hi = min(w, max(0, a_hi - (self.nin - 1)))
         h_lo, h_hi = shard_range(hlen, rank, world)
-        self.ranges = dict(a=(a_lo, a_hi), l=(l_lo, l_hi), h=(h_lo, h_hi))
         dev = f"cuda:{device}"
+        h_sel = None
+        if dist_wm:   # h_query gathered in the block order the distributed map leaves h in (the last index, n - 1, has no base)
+            idx = dist_h_indices(self.n, rank, world)
+            h_sel = torch.from_numpy(idx[idx < hlen]).to(dev)
+            h_lo, h_hi = 0, int(h_sel.numel())
+        self.ranges = dict(a=(a_lo, a_hi), l=(l_lo, l_hi), h=(h_lo, h_hi))
 
         def synth(g2, sd, first, cnt):
             words = (4 if g2 else 2) * L
@@ -117,7 +126,7 @@ class DeviceProver:
             self.lib.check(c.g16_generate_parameters(self.ctx, views, self.nin, nc, self.nvars, C.byref(tw), ptr64(gen1), ptr64(gen2),
                                                      C.byref(out)))
             bufs = dict(a=full["a"][1 + a_lo: 1 + a_hi], b1=full["b1"][1 + a_lo: 1 + a_hi], b2=full["b2"][1 + a_lo: 1 + a_hi],
-                        h=full["h"][h_lo: h_hi], l=full["l"][l_lo: l_hi])
+                        h=full["h"][h_lo: h_hi] if h_sel is None else full["h"].index_select(0, h_sel), l=full["l"][l_lo: l_hi])
             u64 = lambda t: t.cpu().numpy().view(np.uint64).reshape(-1).copy()  # noqa: E731
             fx.update(a0=u64(full["a"][0]), b10=u64(full["b1"][0]), b20=u64(full["b2"][0]))
             self.fixed = fx
@@ -126,7 +135,8 @@ class DeviceProver:
             # index 0 of the a/b generators is query[0]; MSM index i is generator index 1 + i
             bufs = dict(
                 a=synth(False, self.seeds["a"], 1 + a_lo, a_hi - a_lo), b1=synth(False, self.seeds["b1"], 1 + a_lo, a_hi - a_lo),
-                b2=synth(True, self.seeds["b2"], 1 + a_lo, a_hi - a_lo), h=synth(False, self.seeds["h"], h_lo, h_hi - h_lo),
+                b2=synth(True, self.seeds["b2"], 1 + a_lo, a_hi - a_lo),
+                h=synth(False, self.seeds["h"], h_lo, h_hi - h_lo) if h_sel is None else synth(False, self.seeds["h"], 0, hlen).index_select(0, h_sel),
                 l=synth(False, self.seeds["l"], l_lo, l_hi - l_lo))
             q0a = synth(False, self.seeds["a"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
             q0b1 = synth(False, self.seeds["b1"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
@@ -149,14 +159,24 @@ class DeviceProver:
         self.lib.check(c.g16_pk_load(self.ctx, C.byref(view), C.byref(self.pk)))
         self.pk_load_s = time.perf_counter() - t_load   # the "cold" cost: window tables built from device-resident bases, once per key
         self.bufs = bufs  # standard-form copies kept for the CPU-baseline download (the library holds its own)
+        if dist_wm:
+            self.dwm = DistributedWitnessMap(self.lib, self.ctx, self.ck, rank, world, dev)
         # fixed non-zero r, s (zero-knowledge randomness is an input: prover.rs:173-178)
         self.r = z[2].copy()
         self.s = z[3].copy()
 
-    def partial(self, host_z=None):
-        """host_z = None: the witness is already in HBM (the timed configuration); else a host pointer (int) to upload from"""
+    def partial(self, host_z=None, dist=None):
+        """host_z = None: the witness is already in HBM (the timed configuration); else a host pointer (int) to upload from.
+        With the distributed witness map: its four stages + three exchanges over `dist` first, then the MSMs over this rank's h block."""
         part = PartialC()
         zp = C.c_void_p(self.z_dev.data_ptr()) if host_z is None else C.c_void_p(host_z)
+        if self.dwm is not None:
+            t0 = time.perf_counter()
+            h = self.dwm.run(self.z_dev.data_ptr() if host_z is None else host_z, self.nvars, host_z is None, dist)
+            self.dwm_ms = 1e3 * (time.perf_counter() - t0)
+            self.lib.check(self.lib.c.g16_prove_partial_h(self.ctx, self.pk, self.ck, zp, self.nvars, 1 if host_z is None else 0,
+                                                          C.c_void_p(h.data_ptr()), self.dwm.M, 0, C.byref(part)))
+            return part
         self.lib.check(self.lib.c.g16_prove_partial(self.ctx, self.pk, self.ck, zp, self.nvars, 1 if host_z is None else 0, 0, C.byref(part)))
         return part
 
@@ -175,7 +195,7 @@ class DeviceProver:
 
 
 def prove_step(p, dist, device):
-    part = p.partial()
+    part = p.partial(dist=dist)
     if dist is None:
         return p.finalize([part])
     t = torch.frombuffer(bytearray(bytes(part)), dtype=torch.uint8).to(device)
@@ -282,9 +302,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def dist_wm_ok(n_ranks):
+        """the distributed witness map needs a power-of-two rank count <= 16 with ranks^2 | domain size; G16_BENCH_DIST_WM=0
+        keeps the replicated map (A/B)"""
+        lw = n_ranks.bit_length() - 1
+        return (n_ranks > 1 and (1 << lw) == n_ranks and n_ranks <= 16 and 2 * lw <= args.log2 and
+                os.environ.get("G16_BENCH_DIST_WM", "1") != "0")
+
     if args.sim_shards:
         assert world == 1
-        p = DeviceProver(args.curve, args.log2, 1, 0, args.sim_shards, local_rank, args.key)
+        p = DeviceProver(args.curve, args.log2, 1, 0, args.sim_shards, local_rank, args.key, dist_wm=dist_wm_ok(args.sim_shards))
         for _ in range(args.warmup):
             p.partial()
         torch.cuda.synchronize()
@@ -297,10 +324,12 @@ def main():
         p.finalize([part] * args.sim_shards)
         fin = time.perf_counter() - t1
         print(json.dumps({"diagnostic": "per-rank share of a sharded proof (NOT a throughput number)", "sim_shards": args.sim_shards,
-                          "log2": args.log2, "partial_ms": 1e3 * dt, "finalize_ms": 1e3 * fin, "phases": p.timings()}), flush=True)
+                          "log2": args.log2, "partial_ms": 1e3 * dt, "finalize_ms": 1e3 * fin, "phases": p.timings(),
+                          "witness_map": ("distributed: rank 0's four stages, the three exchanges replaced by local copies "
+                                          f"({p.dwm_ms:.2f} ms of partial_ms)") if p.dwm is not None else "replicated"}), flush=True)
         return
     t_setup = time.perf_counter()
-    p = DeviceProver(args.curve, args.log2, 1, rank, world, local_rank, args.key)
+    p = DeviceProver(args.curve, args.log2, 1, rank, world, local_rank, args.key, dist_wm=dist_wm_ok(world))
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     proof = None
@@ -317,6 +346,8 @@ def main():
         for k_, v in tm.items():
             if k_ not in ("bucket_ms", "window_bits", "windows"):
                 phase_acc[k_] = phase_acc.get(k_, 0.0) + v
+        if p.dwm is not None:
+            phase_acc["dist_witness_map_ms"] = phase_acc.get("dist_witness_map_ms", 0.0) + p.dwm_ms
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -407,7 +438,8 @@ def main():
                        "curve": args.curve, "log2_domain": args.log2, "constraints": p.nc, "key": args.key,
                        "untimed_setup_s": round(t_setup, 2), "pk_load_s": round(p.pk_load_s, 3),
                        "witness": "resident in HBM at entry (see value_incl_h2d for the PCIe-inclusive rates)",
-                       "parallelism": f"msm-base-shard x{world}" if world > 1 else "single-gpu"},
+                       "parallelism": (f"msm-base-shard x{world}" + (" + distributed witness map (3 all-to-all)" if p.dwm is not None
+                                                                             else " (witness map replicated)")) if world > 1 else "single-gpu"},
             "roofline": roofline, "roofline_ntt": roofline_ntt, "value_incl_h2d": h2d,
             "phases_ms_per_step": {k_: round(v / args.steps, 3) for k_, v in phase_acc.items()},
         }

@@ -8,8 +8,11 @@
 #include "internal.hpp"
 #include "msm_common.hpp"
 #include "fp30.hpp"
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <future>
+#include <mutex>
 #include <thread>
 #include <new>
 #include <type_traits>
@@ -91,12 +94,23 @@ struct DrainOnError {
     }
 };
 
+struct g16_dwm;
+// multi-device context, device i: its side of the distributed witness map (g16_prove runs the four stages on every device's
+// host thread and moves the chunks between the devices with peer copies -- the single-process form of the all-to-all)
+struct DwmSlot {
+    g16_dwm* dwm = nullptr;
+    uint64_t *work[3] = {nullptr, nullptr, nullptr}, *recv[3] = {nullptr, nullptr, nullptr}, *h_local = nullptr;   // M Fr each
+    uint64_t* z_dev = nullptr;   // num_variables Fr: a host assignment is uploaded once per proof and device
+};
+
 struct g16_circuit {
     int curve;
     g16_ctx* ctx;
     void* dc;  // DeviceCircuit<C>*
     uint64_t domain_size;
     std::vector<g16_circuit*> subs;   // multi-device context: the circuit replicated on every device (dc == nullptr)
+    std::vector<DwmSlot> dist;        // multi-device context whose device count admits the distributed witness map
+    uint64_t num_variables = 0;
 };
 
 template <class C>
@@ -120,6 +134,8 @@ struct g16_pk {
     g16_ctx* ctx;
     void* dp;  // DevicePk<C>*
     std::vector<g16_pk*> subs;        // multi-device context: shard i of the key on device i (dp == nullptr)
+    uint64_t dist_n = 0;              // != 0: the h shards are gathered in the block order of the distributed witness map over a
+                                      // domain of dist_n points (h_query holds dist_n - 1 bases, generator.rs:168)
 };
 
 struct g16_dwm {
@@ -847,6 +863,28 @@ static int for_each_device(int n, Fn fn) {
     return G16_OK;
 }
 
+// reusable barrier for the per-device host threads of one call (C++17: no std::barrier)
+struct HostBarrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n, waiting = 0;
+    uint64_t phase = 0;
+    explicit HostBarrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t my = phase;
+        if (++waiting == n) { waiting = 0; ++phase; cv.notify_all(); return; }
+        cv.wait(lk, [&] { return phase != my; });
+    }
+};
+
+// the distributed witness map runs over `world` ranks when world is a power of two in [2, 16] and world^2 divides the domain
+static bool dist_wm_admissible(int world, uint64_t domain) {
+    if (world < 2 || world > 16 || (world & (world - 1)) != 0) return false;
+    if (domain == 0 || (domain & (domain - 1)) != 0) return false;
+    return domain % ((uint64_t)world * (uint64_t)world) == 0;
+}
+
 extern "C" {
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
@@ -916,6 +954,14 @@ int g16_ctx_create_multi(int curve, const int* device_ids, int n_dev, g16_ctx** 
         }
         c->subs.push_back(sub);
     }
+    // direct xGMI copies between the devices (the exchange of the distributed witness map); a refusal only means that
+    // hipMemcpyPeerAsync stages through the host
+    for (int a = 0; a < n_dev; ++a)
+        for (int b = 0; b < n_dev; ++b)
+            if (device_ids[a] != device_ids[b] && hipSetDevice(device_ids[a]) == hipSuccess) {
+                (void)hipDeviceEnablePeerAccess(device_ids[b], 0);
+                (void)hipGetLastError();
+            }
     *out = c;
     return G16_OK;
 }
@@ -966,11 +1012,26 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
         h->subs.assign((size_t)n, nullptr);
         const uint64_t m = view->a.count, w = view->l.count, hl = view->h.count, skip = m - w;
         const size_t g1b = (ctx->curve == G16_BLS12_381 ? 12 : 8), g2b = 2 * g1b;   // u64 limbs per G1 / G2 affine point
+        // h: when the device count admits the distributed witness map over the key's domain (hl + 1 points, generator.rs:168),
+        // shard i holds the bases of ITS block of h -- indices (i blk + j) + M k1 in the order [k1][j], the last one (n - 1) has
+        // no base -- instead of a contiguous range; g16_prove then never replicates the transforms
+        const bool dist_h = !(view->flags & G16_PK_DEVICE_PTRS) && view->h.points && dist_wm_admissible(n, hl + 1);
+        if (dist_h) h->dist_n = hl + 1;
         const int rc = for_each_device(n, [&](int i) -> int {
             g16_pk_view v = *view;
             const uint64_t a_lo = m * (uint64_t)i / n, a_hi = m * (uint64_t)(i + 1) / n;
             const uint64_t l_lo = std::min(w, a_lo > skip ? a_lo - skip : 0), l_hi = std::min(w, a_hi > skip ? a_hi - skip : 0);
             const uint64_t h_lo = hl * (uint64_t)i / n, h_hi = hl * (uint64_t)(i + 1) / n;
+            std::vector<uint64_t> hblock;
+            if (dist_h) {
+                const uint64_t M = (hl + 1) / (uint64_t)n, blk = M / (uint64_t)n;
+                hblock.reserve((size_t)(M * g1b));
+                for (uint64_t k1 = 0; k1 < (uint64_t)n; ++k1)
+                    for (uint64_t j = 0; j < blk; ++j) {
+                        const uint64_t idx = (uint64_t)i * blk + j + M * k1;
+                        if (idx < hl) hblock.insert(hblock.end(), view->h.points + idx * g1b, view->h.points + (idx + 1) * g1b);
+                    }
+            }
             auto cut = [](const g16_query& q, uint64_t lo, uint64_t hi, size_t limbs) {
                 g16_query r;
                 r.points = q.points ? q.points + lo * limbs : nullptr;
@@ -983,6 +1044,7 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
             v.b_g2 = cut(view->b_g2, a_lo, a_hi, g2b);
             v.l = cut(view->l, l_lo, l_hi, g1b);
             v.h = cut(view->h, h_lo, h_hi, g1b);
+            if (dist_h) { v.h.points = hblock.data(); v.h.count = hblock.size() / g1b; v.h.start = 0; }
             return g16_pk_load(ctx->subs[(size_t)i], &v, &h->subs[(size_t)i]);
         });
         if (rc) { g16_pk_free(h); return rc; }
@@ -1019,6 +1081,22 @@ int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_input
         });
         if (rc) { g16_circuit_free(h); return rc; }
         h->domain_size = h->subs[0]->domain_size;
+        h->num_variables = num_variables;
+        if (dist_wm_admissible(n, h->domain_size)) {
+            h->dist.assign((size_t)n, DwmSlot());
+            const uint64_t M = h->domain_size / (uint64_t)n;
+            const int rc2 = for_each_device(n, [&](int i) -> int {
+                DwmSlot& sl = h->dist[(size_t)i];
+                G16_TRY(g16_dwm_create(ctx->subs[(size_t)i], h->subs[(size_t)i], i, n, &sl.dwm));
+                for (int k = 0; k < 3; ++k) {
+                    if (hipMalloc((void**)&sl.work[k], M * 32) != hipSuccess || hipMalloc((void**)&sl.recv[k], M * 32) != hipSuccess) return G16_ERR_OOM;
+                }
+                if (hipMalloc((void**)&sl.h_local, M * 32) != hipSuccess || hipMalloc((void**)&sl.z_dev, (num_variables ? num_variables : 1) * 32) != hipSuccess)
+                    return G16_ERR_OOM;
+                return G16_OK;
+            });
+            if (rc2) { g16_circuit_free(h); return rc2; }
+        }
         *out = h;
         return G16_OK;
     }
@@ -1029,6 +1107,13 @@ int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_input
 void g16_circuit_free(g16_circuit* c) {
     if (!c) return;
     if (!c->ctx->subs.empty()) {
+        for (size_t i = 0; i < c->dist.size(); ++i) {
+            DwmSlot& sl = c->dist[i];
+            (void)hipSetDevice(c->ctx->subs[i]->device);
+            g16_dwm_free(sl.dwm);
+            for (int k = 0; k < 3; ++k) { (void)hipFree(sl.work[k]); (void)hipFree(sl.recv[k]); }
+            (void)hipFree(sl.h_local); (void)hipFree(sl.z_dev);
+        }
         for (g16_circuit* sub : c->subs) g16_circuit_free(sub);
         delete c;
         return;
@@ -1080,16 +1165,71 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
             for (g16_ctx* sub : ctx->subs) if (sub->device != ctx->subs[0]->device) return G16_ERR_BAD_ARG;
         const double t0 = now_ms();
         std::vector<g16_partial> parts((size_t)n);
-        int rc = for_each_device(n, [&](int i) -> int {
-            return g16_prove_partial(ctx->subs[(size_t)i], pk->subs[(size_t)i], circuit->subs[(size_t)i], full_assignment, n_assign,
-                                     assignment_on_device, skip_b_g1, &parts[(size_t)i]);
-        });
+        if (pk->dist_n && (circuit->dist.empty() || pk->dist_n != circuit->domain_size)) {
+            g_last_error = "the key's h_query does not belong to this circuit's domain (h_query must hold domain_size - 1 bases)";
+            return G16_ERR_BAD_LENGTH;
+        }
+        int rc;
+        double dwm_ms = 0.0;
+        if (pk->dist_n) {
+            // distributed witness map: every device's thread runs its four stages; after stages 0, 1 (a, b, c) and 2 (the quotient)
+            // device i PULLS chunk i of every device's work array into slot q of its recv array (peer copies over xGMI), the
+            // barriers stand for the collective's synchronisation; then the MSMs over this device's block of h
+            if (n_assign != circuit->num_variables) return G16_ERR_BAD_LENGTH;
+            HostBarrier bar(n);
+            std::atomic<int> failed{0};
+            const uint64_t M = circuit->domain_size / (uint64_t)n, blk = M / (uint64_t)n;
+            rc = for_each_device(n, [&](int i) -> int {
+                g16_ctx* sub = ctx->subs[(size_t)i];
+                const DwmSlot& sl = circuit->dist[(size_t)i];
+                int my = G16_OK;
+                auto step = [&](auto fn) {   // every thread passes every barrier, whatever failed where
+                    if (!failed.load() && my == G16_OK) { my = fn(); if (my) failed.store(1); }
+                    bar.wait();
+                };
+                const uint64_t* zp = full_assignment;
+                step([&]() -> int {
+                    G16_HIP_TRY(hipSetDevice(sub->device));
+                    if (!assignment_on_device) {
+                        G16_HIP_TRY(hipMemcpyAsync(sl.z_dev, full_assignment, n_assign * 32, hipMemcpyHostToDevice, sub->stream));
+                        G16_HIP_TRY(hipStreamSynchronize(sub->stream));
+                        zp = sl.z_dev;
+                    }
+                    return G16_OK;
+                });
+                const double tw = now_ms();
+                for (int st = 0; st < 4; ++st) {
+                    step([&]() -> int { return g16_dwm_stage(sub, sl.dwm, st, zp, n_assign, 1, sl.work, sl.recv, sl.h_local); });
+                    if (st == 3) break;
+                    step([&]() -> int {
+                        G16_HIP_TRY(hipSetDevice(sub->device));
+                        for (int a = 0; a < (st < 2 ? 3 : 1); ++a)
+                            for (int q = 0; q < n; ++q)
+                                G16_HIP_TRY(hipMemcpyPeerAsync(sl.recv[a] + (uint64_t)q * blk * 4, sub->device,
+                                                               circuit->dist[(size_t)q].work[a] + (uint64_t)i * blk * 4, ctx->subs[(size_t)q]->device,
+                                                               blk * 32, sub->stream));
+                        G16_HIP_TRY(hipStreamSynchronize(sub->stream));
+                        return G16_OK;
+                    });
+                }
+                if (i == 0) dwm_ms = now_ms() - tw;
+                if (failed.load() || my) return my ? my : G16_ERR_INTERNAL;
+                return g16_prove_partial_h(sub, pk->subs[(size_t)i], circuit->subs[(size_t)i], zp, n_assign, 1, sl.h_local, M, skip_b_g1,
+                                           &parts[(size_t)i]);
+            });
+        } else {
+            rc = for_each_device(n, [&](int i) -> int {
+                return g16_prove_partial(ctx->subs[(size_t)i], pk->subs[(size_t)i], circuit->subs[(size_t)i], full_assignment, n_assign,
+                                         assignment_on_device, skip_b_g1, &parts[(size_t)i]);
+            });
+        }
         if (rc) return rc;
         rc = g16_prove_finalize(ctx->subs[0], pk->subs[0], parts.data(), n, r, s, out);
         // timings: the slowest device's phases (the proof waits for it), wall time of the whole call
         int slow = 0;
         for (int i = 1; i < n; ++i) if (ctx->subs[(size_t)i]->tm.total_ms > ctx->subs[(size_t)slow]->tm.total_ms) slow = i;
         ctx->tm = ctx->subs[(size_t)slow]->tm;
+        if (pk->dist_n) ctx->tm.witness_map_ms = dwm_ms;   // device 0's four stages + three exchanges (host clock)
         ctx->tm.finish_ms = ctx->subs[0]->tm.finish_ms;
         ctx->tm.total_ms = now_ms() - t0;
         return rc;

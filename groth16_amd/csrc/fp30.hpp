@@ -108,16 +108,29 @@ struct Fp30 {
 #endif
     }
     // ---- double-width column primitives (T has 2*NL 64-bit columns) -----------------------------
-    // T = a*b as NL^2 limb products; every column <= NL * 2^60: no overflow, no carries
-    G16_HD static void wide_mul(uint64_t* T, const Fp30& a, const Fp30& b) {
+    // One sweep of limb products adds CNT(c) = min(c + 1, 2 NL - 1 - c) products (each < 2^60) to column c.  A 64-bit column
+    // holds 15 of them plus the small carries that travel with it, so sweeps can pile up in a column WITHOUT any carry work
+    // until (sweeps so far + 1) * CNT(c) would pass 15; only then is the column "relaxed" (wide_relax), and only that column:
+    // for NL = 13 that is 11 of 25 columns between a product and its reduction, none at all for NL <= 7.
+    // The column type is a template parameter so that the host self-test can run every routine with 128-bit columns beside the
+    // 64-bit ones on all-ones limbs and demand identical results (no overflow anywhere).
+#ifndef G16_RELAX_LIMIT
+#define G16_RELAX_LIMIT 15   // products (< 2^60 each) a 64-bit column holds with room for the carries (the 128-bit shadow self-test on
+                             // all-ones limbs still passes at 17 and fails at 20)
+#endif
+    static constexpr int col_count(int c) { return c + 1 < 2 * NL - 1 - c ? c + 1 : 2 * NL - 1 - c; }
+    // T = a*b as NL^2 limb products
+    template <class U>
+    G16_HD static void wide_mul(U* T, const Fp30& a, const Fp30& b) {
         G16_UNROLL for (int c = 0; c < 2 * NL; ++c) T[c] = 0;
         G16_UNROLL for (int i = 0; i < NL; ++i) {
             G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)a.l[i] * b.l[j];
         }
     }
     // T = a*a with the symmetric products taken once against the doubled operand: NL(NL+1)/2 multiply-adds.
-    // A column holds <= NL/2 doubled products (< 2^61) and one square (< 2^60): <= 6.5 * 2^61 < 2^64 for NL = 13.
-    G16_HD static void wide_sqr(uint64_t* T, const Fp30& a) {
+    // A column holds <= CNT/2 doubled products (< 2^61) and one square: the same magnitude as CNT plain products.
+    template <class U>
+    G16_HD static void wide_sqr(U* T, const Fp30& a) {
         G16_UNROLL for (int c = 0; c < 2 * NL; ++c) T[c] = 0;
         G16_UNROLL for (int i = 0; i < NL; ++i) {
             T[2 * i] += (uint64_t)a.l[i] * a.l[i];
@@ -125,42 +138,94 @@ struct Fp30 {
             G16_UNROLL for (int j = i + 1; j < NL; ++j) T[i + j] += (uint64_t)a2 * a.l[j];
         }
     }
-    // T += a*b; T must be normalised (columns < 2^30 + small) on entry
-    G16_HD static void wide_mul_add(uint64_t* T, const Fp30& a, const Fp30& b) {
+    // T += a*b (one more sweep; the caller relaxes in between)
+    template <class U>
+    G16_HD static void wide_mul_add(U* T, const Fp30& a, const Fp30& b) {
         G16_UNROLL for (int i = 0; i < NL; ++i) {
             G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)a.l[i] * b.l[j];
         }
     }
-    // one carry sweep -> every column < 2^30 (the top column takes the rest)
-    G16_HD static void wide_normalize(uint64_t* T) {
+    // SWEEPS sweeps have been accumulated and one more (a product sweep or the reduction) follows: every column that could
+    // not absorb it hands its high word to the next column -- T[c] = lo32 + hi32 * 2^32 and 2^32 = 4 * 2^30, so
+    // T[c + 1] += 4 * hi32: one multiply-add and one register clear instead of the shift / mask / 64-bit add of a full carry
+    // step.  The column keeps < 2^32 (not < 2^30: nothing needs that before the reduction's own carry chain).
+    template <int SWEEPS, class U>
+    G16_HD static void wide_relax(U* T) {
+#ifdef G16_FP30_FULL_NORMALIZE
+        wide_normalize(T);
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the factor 4 is made opaque so that the compiler keeps ONE v_mad_u64_u32 (hi32 * 4 + T[c + 1]); written as a shift it
+        // becomes a 64-bit shift, two masks and a 64-bit add -- as expensive as the full carry step this replaces
+        uint32_t four = 4u;
+        asm("" : "+s"(four));
+        G16_UNROLL for (int c = 0; c + 1 < 2 * NL; ++c) {
+            if ((SWEEPS + 1) * col_count(c) > G16_RELAX_LIMIT) {
+                T[c + 1] += (uint64_t)(uint32_t)(T[c] >> 32) * four;
+                T[c] = (U)(uint32_t)T[c];
+            }
+        }
+#else
+        G16_UNROLL for (int c = 0; c + 1 < 2 * NL; ++c) {
+            if ((SWEEPS + 1) * col_count(c) > G16_RELAX_LIMIT) {
+                T[c + 1] += (T[c] >> 32) << 2;
+                T[c] &= (U)0xffffffffu;
+            }
+        }
+#endif
+#endif
+    }
+    // one full carry sweep -> every column < 2^30 (the top column takes the rest)
+    template <class U>
+    G16_HD static void wide_normalize(U* T) {
         G16_UNROLL for (int c = 0; c + 1 < 2 * NL; ++c) {
             T[c + 1] += T[c] >> 30;
             T[c] &= MASK;
         }
     }
-    // Montgomery reduction of a normalised T (value < ~400 p^2): returns T / R' mod p, < p (1 + T/(R' p))
-    G16_HD static Fp30 wide_redc(uint64_t* T) {
-        uint64_t carry = 0;
+    // Montgomery reduction of T (value < ~400 p^2; columns relaxed for one more sweep): returns T / R' mod p, < p (1 + T/(R' p))
+    template <class U>
+    G16_HD static Fp30 wide_redc(U* T) {
+        U carry = 0;
         G16_UNROLL for (int i = 0; i < NL; ++i) {
             T[i] += carry;
             const uint32_t m = ((uint32_t)T[i] * P::PINV30) & MASK;
-            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)m * P::p30(j);  // column again gets <= NL products
+            G16_UNROLL for (int j = 0; j < NL; ++j) T[i + j] += (uint64_t)m * P::p30(j);  // column c again gets <= CNT(c) products
             carry = T[i] >> 30;  // low 30 bits are zero now
         }
         Fp30 r;
         G16_UNROLL for (int j = 0; j < NL; ++j) {
-            const uint64_t v = T[NL + j] + carry;
+            const U v = T[NL + j] + carry;
             r.l[j] = (j == NL - 1) ? (uint32_t)v : ((uint32_t)v & MASK);
             carry = v >> 30;
         }
         return r;
     }
-    G16_HD Fp30 mul_impl(const Fp30& b) const {
-        uint64_t T[2 * NL];
+    template <class U>
+    G16_HD Fp30 mul_cols(const Fp30& b) const {
+        U T[2 * NL];
         wide_mul(T, *this, b);
-        wide_normalize(T);
+        wide_relax<1>(T);
         return wide_redc(T);
     }
+    template <class U>
+    G16_HD Fp30 sqr_cols() const {
+        U T[2 * NL];
+        wide_sqr(T, *this);
+        wide_relax<1>(T);
+        return wide_redc(T);
+    }
+    template <class U>
+    G16_HD static Fp30 mul_sub_cols(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) {
+        U T[2 * NL];
+        const Fp30 nd = d.neg2();
+        wide_mul(T, a, b);
+        wide_relax<1>(T);
+        wide_mul_add(T, c, nd);
+        wide_relax<2>(T);
+        return wide_redc(T);
+    }
+    G16_HD Fp30 mul_impl(const Fp30& b) const { return mul_cols<uint64_t>(b); }
     G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
     // a*b - c*d with ONE Montgomery reduction (the double-width sums share it): 3 NL^2 multiply-adds instead of 4 NL^2.
     // Requires d < 2p and a*b + 2p*c < ~400 p^2; output < 1.2p for the bounds the group formulas feed it.
@@ -168,23 +233,14 @@ struct Fp30 {
 #if defined(G16_FP30_OUTLINE) || defined(G16_NO_MUL_SUB)
         return a.mul(b).template sub<2>(c.mul(d));
 #else
-        uint64_t T[2 * NL];
-        const Fp30 nd = d.neg2();
-        wide_mul(T, a, b);
-        wide_normalize(T);
-        wide_mul_add(T, c, nd);
-        wide_normalize(T);
-        return wide_redc(T);
+        return mul_sub_cols<uint64_t>(a, b, c, d);
 #endif
     }
     G16_HD Fp30 sqr() const {
 #if defined(G16_FP30_OUTLINE) || defined(G16_FP30_NO_SQR)
         return mul(*this);
 #else
-        uint64_t T[2 * NL];
-        wide_sqr(T, *this);
-        wide_normalize(T);
-        return wide_redc(T);
+        return sqr_cols<uint64_t>();
 #endif
     }
 
@@ -232,8 +288,11 @@ struct Fp30 {
     // accumulator trait constants (see Acc30): bounds of this field's product outputs are < 1.5p
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD Fp30 settle() const { return *this; }
+// Two waves per SIMD (<= 256 registers): at 257 the kernel silently drops to ONE wave per SIMD and loses ~20 % (measured: the
+// round-2 DIRECT template parameter cost 10.1 -> 12.5 ms per pass that way).  With the fused Y3 the allocator spills 18 dwords
+// to scratch instead -- still the faster configuration (profiles/r02_ab_g1_occupancy.txt).
 #ifndef G16_ACC_MIN_WAVES
-#define G16_ACC_MIN_WAVES 1
+#define G16_ACC_MIN_WAVES 2
 #endif
     static constexpr int ACC_MIN_WAVES = G16_ACC_MIN_WAVES;
     static constexpr bool ACC_PREFETCH = true;
@@ -345,14 +404,14 @@ struct Fp2x30 {
         Fp2x30 r;
         const B nb1 = o.c1.neg16();           // 16p - b1
         B::wide_mul(T, c0, o.c0);             // a0 b0 + a1 (16p - b1)  ==  a0 b0 - a1 b1  (mod p)
-        B::wide_normalize(T);
+        B::template wide_relax<1>(T);
         B::wide_mul_add(T, c1, nb1);
-        B::wide_normalize(T);
+        B::template wide_relax<2>(T);
         r.c0 = B::wide_redc(T);
         B::wide_mul(T, c0, o.c1);             // a0 b1 + a1 b0
-        B::wide_normalize(T);
+        B::template wide_relax<1>(T);
         B::wide_mul_add(T, c1, o.c0);
-        B::wide_normalize(T);
+        B::template wide_relax<2>(T);
         r.c1 = B::wide_redc(T);
         return r;
     }
@@ -504,11 +563,16 @@ struct Fp2p30 {
         const B x1 = sel(hi, oa, ma);                 // lane0: a0      lane1: a0
         const B x2 = sel(hi, ma, oa);                 // lane0: a1      lane1: a1
         const B y2 = sel(hi, ob, ob.neg16());         // lane0: 16p-b1  lane1: b0
-        uint64_t T[2 * B::NL];
-        B::wide_mul(T, x1, mb);                       // lane0: a0 b0   lane1: a0 b1
-        B::wide_normalize(T);
+        return pair_cols<uint64_t>(x1, mb, x2, y2);
+    }
+    // x1 y1 + x2 y2 under one reduction
+    template <class U>
+    G16_HD static B pair_cols(const B& x1, const B& y1, const B& x2, const B& y2) {
+        U T[2 * B::NL];
+        B::wide_mul(T, x1, y1);                       // lane0: a0 b0   lane1: a0 b1
+        B::template wide_relax<1>(T);
         B::wide_mul_add(T, x2, y2);                   // lane0: + a1(16p-b1)   lane1: + a1 b0
-        B::wide_normalize(T);
+        B::template wide_relax<2>(T);
         return B::wide_redc(T);
     }
     G16_HD static B pair_sqr(bool hi, const B& m, const B& o) {
@@ -527,13 +591,13 @@ struct Fp2p30 {
         const B z2 = sel(hi, od.neg2(), od);          // lane0: d1      lane1: 2p-d0
         uint64_t T[2 * B::NL];
         B::wide_mul(T, a0, mb);
-        B::wide_normalize(T);
+        B::template wide_relax<1>(T);
         B::wide_mul_add(T, a1, y2);
-        B::wide_normalize(T);
+        B::template wide_relax<2>(T);
         B::wide_mul_add(T, c0, z1);
-        B::wide_normalize(T);
+        B::template wide_relax<3>(T);
         B::wide_mul_add(T, c1, z2);
-        B::wide_normalize(T);
+        B::template wide_relax<4>(T);
         return B::wide_redc(T);
     }
     // Measured (profiles/r02_ab_mul_sub.txt, 2^22, same box): the fused form is 4.7 % FASTER for G1 (Fp30::mul_sub) but 5 %

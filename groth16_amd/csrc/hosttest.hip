@@ -86,6 +86,46 @@ struct SelfTest {
         return 0;
     }
 
+    // Column-overflow check of the carry-free product routines (fp30.hpp: wide_mul / wide_relax / wide_redc): every routine is
+    // run twice, with 64-bit and with 128-bit columns, on the worst limbs the representation allows (all 2^30 - 1) and on
+    // random limbs.  The 128-bit run cannot overflow; identical limbs out mean the 64-bit run did not either.
+    template <class R30>
+    static int selftest_columns(uint64_t seed, int iters) {
+        typedef unsigned __int128 U128;
+        uint64_t st = seed ^ 0xC0;
+        for (int it = 0; it < iters + 4; ++it) {
+            R30 a, b, c, d;
+            for (int i = 0; i < R30::NL; ++i) {
+                const uint32_t worst = R30::MASK;
+                a.l[i] = it < 2 ? worst : (uint32_t)sm_next(st) & R30::MASK;
+                b.l[i] = (it == 0 || it == 2) ? worst : (uint32_t)sm_next(st) & R30::MASK;
+                c.l[i] = it < 3 ? worst : (uint32_t)sm_next(st) & R30::MASK;
+                d.l[i] = it < 4 ? worst : (uint32_t)sm_next(st) & R30::MASK;
+            }
+            if (!a.template mul_cols<uint64_t>(b).same_limbs(a.template mul_cols<U128>(b))) return 601;
+            if (!a.template sqr_cols<uint64_t>().same_limbs(a.template sqr_cols<U128>())) return 602;
+            // two- and four-sweep forms (Fq2 products, fused differences); d is fed as-is where the routine negates it
+            {
+                uint64_t T[2 * R30::NL];
+                U128 W[2 * R30::NL];
+                R30::wide_mul(T, a, b); R30::wide_mul(W, a, b);
+                R30::template wide_relax<1>(T); R30::template wide_relax<1>(W);
+                R30::wide_mul_add(T, c, d); R30::wide_mul_add(W, c, d);
+                R30::template wide_relax<2>(T); R30::template wide_relax<2>(W);
+                uint64_t T2[2 * R30::NL];
+                U128 W2[2 * R30::NL];
+                for (int k = 0; k < 2 * R30::NL; ++k) { T2[k] = T[k]; W2[k] = W[k]; }
+                if (!R30::wide_redc(T2).same_limbs(R30::wide_redc(W2))) return 603;
+                R30::wide_mul_add(T, b, c); R30::wide_mul_add(W, b, c);
+                R30::template wide_relax<3>(T); R30::template wide_relax<3>(W);
+                R30::wide_mul_add(T, a, d); R30::wide_mul_add(W, a, d);
+                R30::template wide_relax<4>(T); R30::template wide_relax<4>(W);
+                if (!R30::wide_redc(T).same_limbs(R30::wide_redc(W))) return 604;
+            }
+        }
+        return 0;
+    }
+
     // batched-affine arithmetic (batch_affine.hpp): the division-step inverse against Fermat's, the lane-pair Fq2 inverse, and
     // the tree levels themselves -- AffineLevel::run executed lane by lane on the CPU over a padded, bucket-sorted entry list
     // with every exceptional pair in it (identity bases, P + P at level 0 and at level 1, P + (-P), holes), compared bucket
@@ -177,7 +217,11 @@ struct SelfTest {
     static int selftest30(uint64_t seed, int iters) {
         uint64_t st = seed;
         {
-            const int rc = selftest_fr30(seed, iters);
+            int rc = selftest_columns<Fp30<typename Fr::Params>>(seed, iters);
+            if (rc) return rc;
+            rc = selftest_columns<F30>(seed, iters);
+            if (rc) return rc;
+            rc = selftest_fr30(seed, iters);
             if (rc) return rc;
         }
         {

@@ -55,9 +55,12 @@ __global__ void gen_powers_kernel(Fr* __restrict__ out, size_t n, PowTable<Fr> t
 
 // R stages (a radix-2^R block) on every group of 2^R tile elements whose indices differ in the R bits [p0, p0+R):
 // load from the LDS planes, R x 2^(R-1) butterflies in registers, store back.
+// unit0: at global stage 0 every twiddle is w^0 = 1 and the product is skipped -- DIT: the caller guarantees that the stage's
+// inputs are reduced (< 2p: canonical data or a pre-scale product); DIF: the difference stays lazy (< 2^(kdone + 2) p), which
+// the canonicalising / pre-scale product that always follows a DIF stage 0 absorbs.
 template <class P, bool DIT, int R, class GIdx>
 __device__ __forceinline__ void ntt30_round(uint32_t* lds, const Fp<P>* __restrict__ tw, int log_n, int s_lo, int q0, int TT, uint32_t E,
-                                            int done, const GIdx& gidx) {
+                                            int done, const GIdx& gidx, bool unit0) {
     typedef Fp30<P> F;
     constexpr int NL = F::NL;
     constexpr int NE = 1 << R;
@@ -81,6 +84,12 @@ __device__ __forceinline__ void ntt30_round(uint32_t* lds, const Fp<P>* __restri
                     // twiddle exponent = (global index of the lower element) mod 2^s, scaled to the n/2-entry table
                     const uint64_t gi = gbase + ((uint64_t)j << (s_lo + q0));
                     const uint64_t widx = (gi & ((1ull << s) - 1)) << (log_n - 1 - s);
+                    if (unit0 && s == 0) {   // uniform across the workgroup
+                        const F u = x[j], v = x[j2];
+                        x[j] = u.add(v);
+                        x[j2] = DIT ? u.template sub<2>(v) : u.sub_pow2(v, kdone);
+                        continue;
+                    }
                     const F w = F::unpack(tw[widx].v);
                     if (DIT) {
                         const F v = x[j2].mul_impl(w);           // < 1.01 p
@@ -152,9 +161,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(Fp<P>* __restri
     while (done < K) {
         const int R = (K - done) >= 3 ? 3 : (K - done);
         const int q0 = DIT ? done : (K - done - R);    // first (lowest) stage of this round, relative to s_lo
-        if (R == 3) ntt30_round<P, DIT, 3>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx);
-        else if (R == 2) ntt30_round<P, DIT, 2>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx);
-        else ntt30_round<P, DIT, 1>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx);
+        if (R == 3) ntt30_round<P, DIT, 3>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx, true);
+        else if (R == 2) ntt30_round<P, DIT, 2>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx, true);
+        else ntt30_round<P, DIT, 1>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx, true);
         __syncthreads();
         done += R;
     }
@@ -191,9 +200,11 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(Fp<P>* __res
     for (int done = 0; done < K;) {
         const int R = (K - done) >= 3 ? 3 : (K - done);
         const int q0 = K - done - R;
-        if (R == 3) ntt30_round<P, false, 3>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx);
-        else if (R == 2) ntt30_round<P, false, 2>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx);
-        else ntt30_round<P, false, 1>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx);
+        // (without a pre-scale the DIT half below multiplies only the odd element of a stage-0 pair; DIF's lazy difference is
+        // such an element, its lazy sum is bounded like every other DIF sum: unit0 is safe either way)
+        if (R == 3) ntt30_round<P, false, 3>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx, true);
+        else if (R == 2) ntt30_round<P, false, 2>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx, true);
+        else ntt30_round<P, false, 1>(lds, tw_dif, log_n, 0, q0, 0, E, done, gidx, true);
         __syncthreads();
         done += R;
     }
@@ -209,9 +220,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(Fp<P>* __res
     }
     for (int done = 0; done < K;) {
         const int R = (K - done) >= 3 ? 3 : (K - done);
-        if (R == 3) ntt30_round<P, true, 3>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx);
-        else if (R == 2) ntt30_round<P, true, 2>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx);
-        else ntt30_round<P, true, 1>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx);
+        const bool unit0 = prescale != nullptr;   // stage-0 inputs are pre-scale products (< 1.01 p); otherwise lazy DIF outputs
+        if (R == 3) ntt30_round<P, true, 3>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx, unit0);
+        else if (R == 2) ntt30_round<P, true, 2>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx, unit0);
+        else ntt30_round<P, true, 1>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx, unit0);
         __syncthreads();
         done += R;
     }

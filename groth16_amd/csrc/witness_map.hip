@@ -123,8 +123,10 @@ __device__ __forceinline__ void dft_small(Fr* v, const SmallRoots<Fr>& roots) {
 
 // one lane per column j < blk of an [N][blk] array (blockIdx.y: which of the chains):
 //   v[i] = in[i blk + j];  v = DFT_N(v, roots_a) .* sc_a[. blk + j];  TWO: v = DFT_N(v, roots_b) .* sc_b[. blk + j];  out[. blk + j] = v
+// (launch bounds: 128 lanes per workgroup, or the compiler assumes 1024, caps the kernel at 128 registers and spills the
+// 16-element column -- 1.3 KB of scratch per lane)
 template <class Fr, int LOGN, bool TWO>
-__global__ void dwm_column_kernel(const Fr* __restrict__ in0, const Fr* __restrict__ in1, const Fr* __restrict__ in2, Fr* __restrict__ out0,
+__global__ __launch_bounds__(128) void dwm_column_kernel(const Fr* __restrict__ in0, const Fr* __restrict__ in1, const Fr* __restrict__ in2, Fr* __restrict__ out0,
                                   Fr* __restrict__ out1, Fr* __restrict__ out2, size_t blk, SmallRoots<Fr> roots_a, const Fr* __restrict__ sc_a,
                                   SmallRoots<Fr> roots_b, const Fr* __restrict__ sc_b) {
     constexpr int N = 1 << LOGN;

@@ -122,24 +122,31 @@ class _Ctx:
 class _DevicePk:
     """g16_pk handle; shard = (index, count) splits every MSM base array into contiguous ranges."""
 
-    def __init__(self, ctx: _Ctx, pk: ProvingKey, num_inputs: int, shard: Tuple[int, int] = (0, 1)):
+    def __init__(self, ctx: _Ctx, pk: ProvingKey, num_inputs: int, shard: Tuple[int, int] = (0, 1), dist_h: bool = False):
+        """dist_h: the h_query shard is this rank's block of the distributed witness map (dist_h_indices) instead of a
+        contiguous range -- the form g16_prove_partial_h expects"""
         self.ctx = ctx
         self.handle = C.c_void_p()
         self._keep = []
         idx, cnt = shard
         rg = shard_ranges(len(pk.a_query) - 1, len(pk.l_query), len(pk.h_query), num_inputs, idx, cnt)
         (a_lo, a_hi), (l_lo, l_hi), (h_lo, h_hi) = rg["a"], rg["l"], rg["h"]
+        h_query = pk.h_query
+        if dist_h:
+            sel = dist_h_indices(len(pk.h_query) + 1, idx, cnt)       # domain size n = len(h_query) + 1 (generator.rs:168)
+            h_query = pk.h_query[sel[sel < len(pk.h_query)]]            # only the very last index of the last rank is n - 1
+            h_lo, h_hi = 0, len(h_query)
 
         def q(arr: np.ndarray, skip: int, lo: int, hi: int) -> QueryC:
             sl = _c(arr[skip + lo: skip + hi])
             self._keep.append(sl)
-            return QueryC(sl.ctypes.data if len(sl) else None, hi - lo, lo)
+            return QueryC(sl.ctypes.data if len(sl) else None, hi - lo, 0 if (dist_h and arr is h_query) else lo)
 
         keep = [_c(x).reshape(-1) for x in (pk.alpha_g1, pk.beta_g1, pk.delta_g1, pk.beta_g2, pk.delta_g2, pk.a_query[0],
                                             pk.b_g1_query[0], pk.b_g2_query[0])]
         self._keep += keep
         view = PkViewC(*[ptr64(k) for k in keep], q(pk.a_query, 1, a_lo, a_hi), q(pk.b_g1_query, 1, a_lo, a_hi),
-                       q(pk.b_g2_query, 1, a_lo, a_hi), q(pk.h_query, 0, h_lo, h_hi), q(pk.l_query, 0, l_lo, l_hi), 0)
+                       q(pk.b_g2_query, 1, a_lo, a_hi), q(h_query, 0, h_lo, h_hi), q(pk.l_query, 0, l_lo, l_hi), 0)
         ctx.lib.check(ctx.lib.c.g16_pk_load(ctx.handle, C.byref(view), C.byref(self.handle)))
         self._keep = []  # the library copied everything
 
@@ -147,6 +154,14 @@ class _DevicePk:
         if self.handle:
             self.ctx.lib.c.g16_pk_free(self.handle)
             self.handle = C.c_void_p()
+
+def dist_h_indices(n: int, rank: int, world: int) -> np.ndarray:
+    """h coefficients rank `rank` of `world` holds after the distributed witness map (g16_dwm_*): the BLOCK indices
+    (rank * blk + j) + M * k1, j < blk = M / world, k1 < world, M = n / world, in the order [k1][j] -- the order its shard of
+    h_query has to be gathered in (include/g16_mi355x.h)."""
+    M = n // world
+    blk = M // world
+    return ((rank * blk + np.arange(blk, dtype=np.int64))[None, :] + (M * np.arange(world, dtype=np.int64))[:, None]).reshape(-1)
 
 
 def _csr_views(m: "ConstraintMatrices"):
@@ -202,13 +217,13 @@ class Groth16:
         self._cks: Dict[int, _DeviceCircuit] = {}
 
     # -- handles -------------------------------------------------------------------------
-    def _pk(self, pk: ProvingKey, num_inputs: int, shard=(0, 1)) -> _DevicePk:
-        key = (id(pk), shard)
+    def _pk(self, pk: ProvingKey, num_inputs: int, shard=(0, 1), dist_h: bool = False) -> _DevicePk:
+        key = (id(pk), shard) if not dist_h else (id(pk), shard, "dist_h")
         if key not in self._pks:
             if pk.curve != self.curve:
                 raise ValueError("proving key is for another curve")
             # the cache entry holds a reference to pk so that id(pk) cannot be recycled while it lives
-            self._pks[key] = (pk, _DevicePk(self._ctx, pk, num_inputs, shard))
+            self._pks[key] = (pk, _DevicePk(self._ctx, pk, num_inputs, shard, dist_h))
         return self._pks[key][1]
 
     def _ck(self, m: ConstraintMatrices) -> _DeviceCircuit:
@@ -347,10 +362,22 @@ class Groth16:
                                         C.byref(part)))
         return bytes(part)
 
+    def prove_partial_h(self, pk: ProvingKey, matrices: ConstraintMatrices, full_assignment: np.ndarray, shard: Tuple[int, int],
+                        h_dev_ptr: int, h_len: int, skip_b_g1: bool = False) -> bytes:
+        """g16_prove_partial_h: the shard's five partial sums with h supplied by the caller (device memory: this rank's block of
+        the distributed witness map); the key shard is the one gathered in that block order (dist_h)"""
+        dpk, dck = self._pk(pk, matrices.num_instance_variables, shard, dist_h=True), self._ck(matrices)
+        z = _c(full_assignment)
+        part = PartialC()
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_prove_partial_h(self._ctx.handle, dpk.handle, dck.handle, z.ctypes.data, z.shape[0], 0, C.c_void_p(h_dev_ptr), h_len,
+                                          int(skip_b_g1), C.byref(part)))
+        return bytes(part)
+
     def prove_finalize(self, pk: ProvingKey, num_inputs: int, parts: Sequence[bytes], r: np.ndarray, s: np.ndarray,
-                       shard: Tuple[int, int] = (0, 1)) -> Proof:
+                       shard: Tuple[int, int] = (0, 1), dist_h: bool = False) -> Proof:
         L = FQ_LIMBS[self.curve]
-        dpk = self._pk(pk, num_inputs, shard)
+        dpk = self._pk(pk, num_inputs, shard, dist_h)   # any shard carries the eight fixed points the glue reads
         arr = (PartialC * len(parts))(*[PartialC.from_buffer_copy(p) for p in parts])
         out = ProofC()
         lb = self._ctx.lib
@@ -376,6 +403,66 @@ def finalize_host(curve: str, pk: "ProvingKey", parts: Sequence[bytes], r: np.nd
     lb = lib()
     lb.check(lb.c.g16_finalize_host(CURVE_ID[curve], C.byref(view), arr, len(parts), ptr64(_c(r)), ptr64(_c(s)), C.byref(out)))
     return Proof(np.array(out.a[: 2 * L], dtype=np.uint64), np.array(out.b[: 4 * L], dtype=np.uint64), np.array(out.c[: 2 * L], dtype=np.uint64))
+
+
+class DistributedWitnessMap:
+    """g16_dwm_*: one rank's side of the distributed witness map (h = witness_map_from_matrices, r1cs_to_qap.rs:172-235, with
+    every n-point transform cut into a local n/world-point transform, a twiddle, ONE all-to-all and a local world-point
+    transform).  The object owns the rank's device buffers (torch tensors: work[3], recv[3], h_local, M = n / world Fr each);
+    the caller owns the exchange -- `run` does it with torch.distributed.all_to_all_single (RCCL over xGMI for backend
+    "nccl"), the single-process tests move the chunks themselves between the ranks' objects."""
+
+    def __init__(self, lib_, ctx_handle, circuit_handle, rank: int, world: int, device):
+        import torch
+
+        self.lib, self.ctx, self.rank, self.world = lib_, ctx_handle, rank, world
+        self.handle = C.c_void_p()
+        lib_.check(lib_.c.g16_dwm_create(ctx_handle, circuit_handle, rank, world, C.byref(self.handle)))
+        self.M = int(lib_.c.g16_dwm_local_size(self.handle))
+        self.blk = self.M // world
+        mk = lambda: torch.empty((self.M, 4), dtype=torch.int64, device=device)  # noqa: E731
+        self.work, self.recv, self.h_local = [mk() for _ in range(3)], [mk() for _ in range(3)], mk()
+        self._wp = (C.c_void_p * 3)(*[t.data_ptr() for t in self.work])
+        self._rp = (C.c_void_p * 3)(*[t.data_ptr() for t in self.recv])
+
+    def stage(self, s: int, z_ptr: int = 0, n_assign: int = 0, on_device: bool = False):
+        """stage 0: full_assignment -> work[0..2];  1: recv[0..2] -> work[0..2];  2: recv[0..2] -> work[0];  3: recv[0] -> h_local.
+        Returns with the device work finished."""
+        self.lib.check(self.lib.c.g16_dwm_stage(self.ctx, self.handle, s, C.c_void_p(z_ptr) if z_ptr else None, n_assign, int(on_device),
+                                                self._wp, self._rp, C.c_void_p(self.h_local.data_ptr())))
+
+    @staticmethod
+    def arrays_after(s: int) -> int:
+        """arrays exchanged after stage s (a, b, c after stages 0 and 1; the quotient after stage 2)"""
+        return 3 if s < 2 else 1
+
+    def run(self, z_ptr: int, n_assign: int, on_device: bool, dist):
+        """all four stages with the exchanges over `dist` (torch.distributed); returns h_local"""
+        import torch
+
+        for s in range(4):
+            self.stage(s, z_ptr if s == 0 else 0, n_assign if s == 0 else 0, on_device)
+            if s < 3:
+                for m in range(self.arrays_after(s)):
+                    src, dst = self.work[m], self.recv[m]
+                    if dist is not None and self.world > 1:
+                        if dist.get_backend() == "nccl":
+                            dist.all_to_all_single(dst, src)      # chunk p of src -> rank p; chunk from rank q -> position q
+                        else:   # gloo (one-GPU / CPU tests) has no all-to-all: gather everything on the host, keep my chunks
+                            mine = src.cpu()
+                            every = [torch.empty_like(mine) for _ in range(self.world)]
+                            dist.all_gather(every, mine)
+                            blk = self.blk
+                            dst.copy_(torch.cat([e[self.rank * blk:(self.rank + 1) * blk] for e in every]))
+                    else:
+                        dst.copy_(src)
+                torch.cuda.synchronize()   # the next stage runs on the library's own stream
+        return self.h_local
+
+    def close(self):
+        if self.handle:
+            self.lib.c.g16_dwm_free(self.handle)
+            self.handle = C.c_void_p()
 
 
 class ShardedProver:

@@ -133,7 +133,10 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out);
  * -> create_proof_with_reduction, src/prover.rs:173-217 -- stays a single g16_prove: g16_pk_load (given the WHOLE key: every
  * query.start == 0, host pointers) cuts the five MSM base arrays into n_dev contiguous shards, one per device;
  * g16_circuit_load replicates the matrices; g16_prove (host full_assignment) runs one host thread per device and folds the
- * n_dev partial records on the host.  g16_prove_partial is the per-device form and is refused on such a context;
+ * n_dev partial records on the host.  When n_dev is a power of two <= 16 with n_dev^2 | domain_size the witness map is
+ * distributed as well (the g16_dwm_* stages below on every device, the all-to-all as peer copies between the devices' buffers
+ * over xGMI) and g16_pk_load gathers every h_query shard in the block order that leaves h in (the key must then be the
+ * circuit's: h_query holds domain_size - 1 bases, generator.rs:168; anything else is G16_ERR_BAD_LENGTH at g16_prove).  g16_prove_partial is the per-device form and is refused on such a context;
  * g16_prove_finalize and the unit-level entry points run on the first device.  device_ids may repeat.  n_dev == 1 is
  * g16_ctx_create. */
 int g16_ctx_create_multi(int curve, const int* device_ids, int n_dev, g16_ctx** out);

@@ -302,15 +302,18 @@ def test_sharded_proof_equals_single(env, orc, g):
 
 
 @pytest.mark.parametrize("curve", CURVES)
-def test_multi_device_context_single_call(orc, g, curve):
+@pytest.mark.parametrize("n_dev", [3, 2, 4])
+def test_multi_device_context_single_call(orc, g, curve, n_dev):
     """g16_ctx_create_multi: ONE g16_prove over a context of several devices -- here the one visible GPU
-    three times -- shards the key inside the library, runs a host thread per device and folds the partial records; the
-    proof equals the oracle's, r = 0 included (prover.rs:98-108), and the per-device form is refused on such a context"""
+    n_dev times -- shards the key inside the library, runs a host thread per device and folds the partial records; the
+    proof equals the oracle's, r = 0 included (prover.rs:98-108), and the per-device form is refused on such a context.
+    n_dev = 3 replicates the witness map; a power of two distributes it (four stages per device, the all-to-all as peer
+    copies between the devices' buffers, h_query sharded in block order)."""
     ck = orc.syn_circuit(curve, 11, 6)
     pk, _ = orc.setup(ck, 4)
     gm, gp = mats_of(g, ck), pk_of(g, pk)
-    with g.Groth16(curve, [0, 0, 0]) as prover:
-        assert prover._ctx.num_devices == 3
+    with g.Groth16(curve, [0] * n_dev) as prover:
+        assert prover._ctx.num_devices == n_dev
         for r, s in ((orc.rand_fr(curve, 91, 1)[0], orc.rand_fr(curve, 92, 1)[0]), (np.zeros(4, dtype=np.uint64), orc.rand_fr(curve, 93, 1)[0])):
             proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
             assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
@@ -323,6 +326,23 @@ def test_multi_device_context_single_call(orc, g, curve):
         r, s = orc.rand_fr(curve, 94, 1)[0], orc.rand_fr(curve, 95, 1)[0]
         proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
         assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+
+
+def test_multi_device_context_padded_domain(orc, g):
+    """a circuit whose domain is padded (MiMC: nc + num_inputs not a power of two) through the distributed path of the
+    multi-device context, and a key that does not belong to the circuit's domain is refused"""
+    curve, cp = "bls12_381", CP["bls12_381"]
+    cs, z = pm.mimc_circuit(cp, 40, 9)
+    ck = circuit_from_pymodel(cp, cs, z)
+    pk, _ = orc.setup(ck, 6)
+    gm, gp = mats_of(g, ck), pk_of(g, pk)
+    r, s = orc.rand_fr(curve, 96, 1)[0], orc.rand_fr(curve, 97, 1)[0]
+    with g.Groth16(curve, [0, 0, 0, 0]) as prover:
+        proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
+        assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+        ck2 = orc.syn_circuit(curve, 10, 2)     # another domain size than the key's
+        with pytest.raises(g.G16Error):
+            prover.create_proof_with_reduction_and_matrices(gp, r, s, mats_of(g, ck2), ck2.num_inputs, ck2.num_constraints, ck2.z)
 
 
 def test_error_paths(env, orc, g):

@@ -1,0 +1,54 @@
+"""Register / scratch budget of the hot kernels, read from the code objects inside the BUILT library (no GPU needed).
+
+The bucket passes and the NTT kernels sit right at resource cliffs the compiler does not warn about: one register past 256 drops
+a kernel from two waves per SIMD to one (round 2: 10.1 -> 12.5 ms per G1 bucket pass), and an unrolled block past LLVM's pragma-
+unroll cap leaves the butterfly registers in scratch memory (NTT 6.3 -> 11.4 ms).  Both regressions were silent -- every parity
+test stayed green -- so the budgets are asserted here."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    import kernel_occupancy
+
+    import groth16_amd
+
+    ks = kernel_occupancy.kernels(groth16_amd.lib().path)
+    assert len(ks) > 40, "could not read the code objects of the built library"
+    return ks
+
+
+def pick(kernels, *subs):
+    hit = {n: k for n, k in kernels.items() if all(s in n for s in subs)}
+    assert hit, f"no kernel matches {subs}"
+    return hit
+
+
+@pytest.mark.parametrize("curve", ["Bls12_381FqP", "Bn254FqP"])
+def test_bucket_pass_keeps_two_waves_per_simd(kernels, curve):
+    # the production walk (sorted entry words) for G1 and the lane-pair G2 kernel
+    for field in ("Fp30<", "Fp2p30<"):
+        for name, k in pick(kernels, "bucket_accumulate30_kernel", field + curve, "false").items():
+            assert k["waves_per_simd"] >= 2, (name, k)
+    # G1: a handful of spilled dwords are tolerated (fused Y3), not a spilled working set
+    for name, k in pick(kernels, "bucket_accumulate30_kernel", "Fp30<" + curve, "false").items():
+        assert k["scratch"] <= 128, (name, k)
+
+
+def test_ntt_kernels_keep_their_butterflies_in_registers(kernels):
+    for name, k in pick(kernels, "ntt30_").items():
+        assert k["scratch"] == 0, (name, k)
+        assert k["waves_per_simd"] >= 2, (name, k)       # two workgroups of 256 lanes per CU (76 KB of LDS each)
+
+
+def test_streaming_kernels_have_no_scratch(kernels):
+    for sub in ("spmv3_kernel", "quotient_kernel", "bitrev_scale_kernel", "class_count_kernel", "class_partition_kernel",
+                "bucket_count_merged_kernel", "bucket_scatter_merged_kernel", "digits_kernel", "dwm_column_kernel"):
+        for name, k in pick(kernels, sub).items():
+            assert k["scratch"] == 0, (name, k)

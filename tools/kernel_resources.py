@@ -21,4 +21,4 @@ for line in out.splitlines():
 for r in rows:
     n = re.sub(r"g16::", "", r["name"])
     n = re.sub(r"\(.*", "", n)[:90]
-    print(f"{n:90s} vgpr={r.get('VGPRs')} scratch={r.get('ScratchSize [bytes/lane]')} occ={r.get('Occupancy [waves/SIMD]')} lds={r.get('LDS Size [bytes/block]')}")
+    print(f"{n:90s} vgpr={r.get('VGPRs')} agpr={r.get('AGPRs')} scratch={r.get('ScratchSize [bytes/lane]')} occ={r.get('Occupancy [waves/SIMD]')} lds={r.get('LDS Size [bytes/block]')}")
