@@ -846,9 +846,19 @@ static void g16_dwm_free_impl(g16_dwm* d) {
     d->dw = nullptr;
 }
 
-// run fn(i) for i < n on n host threads; first non-zero status wins
+// run fn(i) for i < n on n host threads; first non-zero status wins.  serial = true runs them one after the other on the
+// calling thread (the LOAD paths of a context that lists one physical device several times: n concurrent table builds on one
+// GPU buy nothing, and their 9-17 KB/lane scratch demands on sibling queues of one device have aborted inside the HIP runtime
+// in the full test suite -- never in isolation)
 template <class Fn>
-static int for_each_device(int n, Fn fn) {
+static int for_each_device(int n, Fn fn, bool serial = false) {
+    if (serial) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = fn(i);
+            if (rc) return rc;
+        }
+        return G16_OK;
+    }
     std::vector<int> rc((size_t)n, G16_OK);
     std::vector<std::thread> th;
     try {
@@ -883,6 +893,13 @@ static bool dist_wm_admissible(int world, uint64_t domain) {
     if (world < 2 || world > 16 || (world & (world - 1)) != 0) return false;
     if (domain == 0 || (domain & (domain - 1)) != 0) return false;
     return domain % ((uint64_t)world * (uint64_t)world) == 0;
+}
+
+static bool devices_repeat(const g16_ctx* ctx) {
+    for (size_t a = 0; a < ctx->subs.size(); ++a)
+        for (size_t b = a + 1; b < ctx->subs.size(); ++b)
+            if (ctx->subs[a]->device == ctx->subs[b]->device) return true;
+    return false;
 }
 
 extern "C" {
@@ -1046,7 +1063,7 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
             v.h = cut(view->h, h_lo, h_hi, g1b);
             if (dist_h) { v.h.points = hblock.data(); v.h.count = hblock.size() / g1b; v.h.start = 0; }
             return g16_pk_load(ctx->subs[(size_t)i], &v, &h->subs[(size_t)i]);
-        });
+        }, devices_repeat(ctx));
         if (rc) { g16_pk_free(h); return rc; }
         *out = h;
         return G16_OK;
@@ -1078,7 +1095,7 @@ int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_input
         h->subs.assign((size_t)n, nullptr);
         const int rc = for_each_device(n, [&](int i) -> int {
             return g16_circuit_load(ctx->subs[(size_t)i], abc, num_inputs, num_constraints, num_variables, &h->subs[(size_t)i]);
-        });
+        }, devices_repeat(ctx));
         if (rc) { g16_circuit_free(h); return rc; }
         h->domain_size = h->subs[0]->domain_size;
         h->num_variables = num_variables;
@@ -1094,7 +1111,7 @@ int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_input
                 if (hipMalloc((void**)&sl.h_local, M * 32) != hipSuccess || hipMalloc((void**)&sl.z_dev, (num_variables ? num_variables : 1) * 32) != hipSuccess)
                     return G16_ERR_OOM;
                 return G16_OK;
-            });
+            }, devices_repeat(ctx));
             if (rc2) { g16_circuit_free(h); return rc2; }
         }
         *out = h;
@@ -1183,9 +1200,14 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                 g16_ctx* sub = ctx->subs[(size_t)i];
                 const DwmSlot& sl = circuit->dist[(size_t)i];
                 int my = G16_OK;
+                int step_no = 0;
+                const bool dbg = getenv("G16_DEBUG") != nullptr;
                 auto step = [&](auto fn) {   // every thread passes every barrier, whatever failed where
+                    if (dbg) fprintf(stderr, "[g16 multi] device %d step %d begin\n", i, step_no);
                     if (!failed.load() && my == G16_OK) { my = fn(); if (my) failed.store(1); }
+                    if (dbg) fprintf(stderr, "[g16 multi] device %d step %d rc=%d, at barrier\n", i, step_no, my);
                     bar.wait();
+                    ++step_no;
                 };
                 const uint64_t* zp = full_assignment;
                 step([&]() -> int {

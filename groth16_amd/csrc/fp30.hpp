@@ -229,8 +229,12 @@ struct Fp30 {
     G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
     // a*b - c*d with ONE Montgomery reduction (the double-width sums share it): 3 NL^2 multiply-adds instead of 4 NL^2.
     // Requires d < 2p and a*b + 2p*c < ~400 p^2; output < 1.2p for the bounds the group formulas feed it.
+    // OPT-IN (G16_FP30_MUL_SUB).  Measured on the G1 bucket pass (Y3 = R (Q - X3) - Y1 PPP), same box each time: -4.7 % at
+    // equal occupancy, but the fused form needs ~15 more live registers than the 256 that keep two waves per SIMD; held to 256
+    // the allocator spills 18 dwords and the pass is 1.8 % SLOWER than two plain products in 252 registers (9.62 vs 9.45 ms,
+    // profiles/r02_ab_g1_occupancy.txt).  The bucket kernel therefore uses two products.
     G16_HD static Fp30 mul_sub(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) {
-#if defined(G16_FP30_OUTLINE) || defined(G16_NO_MUL_SUB)
+#if defined(G16_FP30_OUTLINE) || !defined(G16_FP30_MUL_SUB)
         return a.mul(b).template sub<2>(c.mul(d));
 #else
         return mul_sub_cols<uint64_t>(a, b, c, d);
@@ -289,8 +293,7 @@ struct Fp30 {
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD Fp30 settle() const { return *this; }
 // Two waves per SIMD (<= 256 registers): at 257 the kernel silently drops to ONE wave per SIMD and loses ~20 % (measured: the
-// round-2 DIRECT template parameter cost 10.1 -> 12.5 ms per pass that way).  With the fused Y3 the allocator spills 18 dwords
-// to scratch instead -- still the faster configuration (profiles/r02_ab_g1_occupancy.txt).
+// round-2 DIRECT template parameter cost 10.1 -> 12.5 ms per pass that way; tests/test_kernel_resources.py now asserts it).
 #ifndef G16_ACC_MIN_WAVES
 #define G16_ACC_MIN_WAVES 2
 #endif
