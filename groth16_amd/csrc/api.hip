@@ -8,6 +8,7 @@
 #include "internal.hpp"
 #include "msm_common.hpp"
 #include "fp30.hpp"
+#include "fixed_base.hpp"
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -127,6 +128,9 @@ struct DevicePk {
     // `count` points, row j = 2^(cj) * query.  0 = no tables (plain bases, per-window buckets).  a, b_g1, b_g2 and l share
     // the witness sort and therefore one window size; h has its own.
     int c_z = 0, c_h = 0;
+    // host: multiples of delta_g1 / delta_g2 for the glue of every proof over this key (fixed_base.hpp)
+    FixedBaseTable<typename C::G1X> delta1_tab;
+    FixedBaseTable<typename C::G2X> delta2_tab;
 };
 
 struct g16_pk {
@@ -228,6 +232,11 @@ struct Impl {
         p->a_query0 = load_pod<G1A>(v->a_query0);
         p->b_g1_query0 = load_pod<G1A>(v->b_g1_query0);
         p->b_g2_query0 = load_pod<G2A>(v->b_g2_query0);
+        {   // ~35 ms of host work, once per key: the three host threads of every later finalize save ~0.6 ms each
+            auto f1 = std::async(std::launch::async, [&]() { p->delta1_tab.build(G1X::from_affine(p->delta_g1)); });
+            p->delta2_tab.build(G2X::from_affine(p->delta_g2));
+            f1.get();
+        }
         const bool dev = (v->flags & G16_PK_DEVICE_PTRS) != 0;
         int rc = G16_OK;
         // window tables (merged windows, msm.hip): a, b_g1, b_g2 and l share the witness sort, hence one window size
@@ -504,7 +513,7 @@ struct Impl {
         G2A beta_g2, delta_g2, b_g2_query0;
     };
     static int finalize_core(const FixedPoints& pk, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
-                             g16_proof* out) {
+                             g16_proof* out, const FixedBaseTable<G1X>* d1 = nullptr, const FixedBaseTable<G2X>* d2 = nullptr) {
         if (n_parts < 1) return G16_ERR_BAD_ARG;
         G1X h_acc = G1X::identity(), l_acc = G1X::identity(), a_msm = G1X::identity(), b1_msm = G1X::identity();
         G2X b2_msm = G2X::identity();
@@ -522,10 +531,12 @@ struct Impl {
         (r * s).to_canonical(rsk);
         const int nb = Fr::Params::BITS;
         const G1X delta1 = G1X::from_affine(pk.delta_g1);
+        static_assert(Fr::N == 8, "scalars are 8 words: fixed_base.hpp walks 32 bytes / 64 nibbles");
+        auto mul_d1 = [&](const uint32_t* k) { return (d1 && d1->ready()) ? d1->mul(k) : delta1.mul_bits(k, nb); };
         // three independent chains of scalar multiplications (the only non-trivial host work): run them on host threads
         // B in G2:  s*delta_g2 + b_g2_query[0] + msm + beta_g2                       (:112-113)
         auto fut_b2 = std::async(std::launch::async, [&]() {
-            G2X g2_b = G2X::from_affine(pk.delta_g2).mul_bits(sk, nb);
+            G2X g2_b = (d2 && d2->ready()) ? d2->mul(sk) : G2X::from_affine(pk.delta_g2).mul_bits(sk, nb);
             g2_b.add_affine(pk.b_g2_query0);
             g2_b.add(b2_msm);
             g2_b.add_affine(pk.beta_g2);
@@ -535,20 +546,20 @@ struct Impl {
         auto fut_rb1 = std::async(std::launch::async, [&]() {
             G1X g1_b = G1X::identity();
             if (!r.is_zero()) {
-                g1_b = delta1.mul_bits(sk, nb);
+                g1_b = mul_d1(sk);
                 g1_b.add_affine(pk.b_g1_query0);
                 g1_b.add(b1_msm);
                 g1_b.add_affine(pk.beta_g1);
             }
-            return g1_b.mul_bits(rk, nb);
+            return mul_window4(g1_b, rk);
         });
         // g_a = r*delta_g1 + a_query[0] + msm + alpha_g1   (calculate_coeff, :90-92, :252-270), then s*g_a (:94)
-        G1X g_a = delta1.mul_bits(rk, nb);
+        G1X g_a = mul_d1(rk);
         g_a.add_affine(pk.a_query0);
         g_a.add(a_msm);
         g_a.add_affine(pk.alpha_g1);
-        const G1X s_g_a = g_a.mul_bits(sk, nb);
-        const G1X r_s_delta_g1 = delta1.mul_bits(rsk, nb);                      // :76
+        const G1X s_g_a = mul_window4(g_a, sk);
+        const G1X r_s_delta_g1 = mul_d1(rsk);                                   // :76
         const G1X r_g1_b = fut_rb1.get();
         const G2X g2_b = fut_b2.get();
         G1X g_c = s_g_a;                                                        // :119-124
@@ -571,7 +582,7 @@ struct Impl {
         const double t0 = now_ms();
         const FixedPoints fp = {pk->alpha_g1, pk->beta_g1, pk->delta_g1, pk->a_query0, pk->b_g1_query0, pk->beta_g2, pk->delta_g2,
                                 pk->b_g2_query0};
-        G16_TRY(finalize_core(fp, parts, n_parts, r_, s_, out));
+        G16_TRY(finalize_core(fp, parts, n_parts, r_, s_, out, &pk->delta1_tab, &pk->delta2_tab));
         const double dt = now_ms() - t0;
         ctx->tm.finish_ms += dt;
         ctx->tm.total_ms += dt;

@@ -3,6 +3,7 @@
 #include "internal.hpp"
 #include "fp30.hpp"
 #include "batch_affine.hpp"
+#include "fixed_base.hpp"
 #include <vector>
 
 using namespace g16;
@@ -82,6 +83,28 @@ struct SelfTest {
                 if (!(canon(d2) == rnv)) return 503;
             }
             if (!(canon(s2) == ru)) return 504;
+        }
+        return 0;
+    }
+
+    // fixed_base.hpp against plain double-and-add: table multiples of a random point and the 4-bit window, scalars incl. 0, 1,
+    // r - 1 and all-ones bytes
+    template <class X, class A>
+    static int selftest_fixed_base(const A& gen, uint64_t seed, int first_code) {
+        uint64_t st = seed ^ 0xFB;
+        uint32_t k0[8];
+        for (int i = 0; i < 8; ++i) k0[i] = (uint32_t)sm_next(st);
+        k0[7] &= 0x0fffffffu;
+        const X p = X::from_affine(gen).mul_bits(k0, 256);
+        FixedBaseTable<X> tab;
+        tab.build(p);
+        for (int it = 0; it < 6; ++it) {
+            uint32_t k[8];
+            for (int i = 0; i < 8; ++i) k[i] = it == 0 ? 0u : it == 1 ? (i == 0 ? 1u : 0u) : it == 2 ? 0xffffffffu : (uint32_t)sm_next(st);
+            if (it == 3) for (int i = 0; i < Fr::N; ++i) k[i] = Fr::Params::mod(i) - (i == 0 ? 1u : 0u);
+            const auto want = p.mul_bits(k, 256).to_affine();
+            if (!(tab.mul(k).to_affine() == want)) return first_code;
+            if (!(mul_window4(p, k).to_affine() == want)) return first_code + 1;
         }
         return 0;
     }
@@ -218,6 +241,10 @@ struct SelfTest {
         uint64_t st = seed;
         {
             int rc = selftest_columns<Fp30<typename Fr::Params>>(seed, iters);
+            if (rc) return rc;
+            rc = selftest_fixed_base<G1X>(C::g1_generator(), seed, 611);
+            if (rc) return rc;
+            rc = selftest_fixed_base<G2X>(C::g2_generator(), seed, 613);
             if (rc) return rc;
             rc = selftest_columns<F30>(seed, iters);
             if (rc) return rc;

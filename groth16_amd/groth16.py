@@ -21,9 +21,49 @@ _MODULUS_R = {
     "bn254": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
 }
 
+_MODULUS_Q = {
+    "bls12_381": 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+    "bn254": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+}
+# the curves' standard generators (x, y; G2 coordinates as (c0, c1)): IETF pairing-friendly-curves draft / EIP-197
+_GENERATORS = {
+    "bls12_381": (
+        (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+         0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1),
+        ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+          0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+         (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+          0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))),
+    "bn254": (
+        (1, 2),
+        ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+          11559732032986387107991004021392285783925812861821192530917403151452391805634),
+         (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+          4082367875863433681332203403145435568316851327593401208105741076214120093531))),
+}
+
 
 def _c(a: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _limbs(v: int, n: int) -> List[int]:
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+
+
+def _fq_mont(curve: str, coords: Sequence[int]) -> np.ndarray:
+    """integers mod q -> concatenated Montgomery limbs (the in-memory form of an affine point's coordinates)"""
+    L, q = FQ_LIMBS[curve], _MODULUS_Q[curve]
+    return np.array([w for x in coords for w in _limbs((x << (64 * L)) % q, L)], dtype=np.uint64)
+
+
+def _rand_fr(curve: str, rng=None, nonzero: bool = False) -> np.ndarray:
+    """F::rand(rng) as Montgomery limbs; rng: anything with getrandbits (random.Random), default the OS source"""
+    p = _MODULUS_R[curve]
+    while True:
+        v = (rng.getrandbits(512) if rng is not None else secrets.randbits(512)) % p
+        if v or not nonzero:
+            return np.array(_limbs((v << 256) % p, 4), dtype=np.uint64)
 
 
 @dataclass
@@ -215,6 +255,7 @@ class Groth16:
         self._ctx = _Ctx(curve, device)
         self._pks: Dict[Tuple[int, Tuple[int, int]], _DevicePk] = {}
         self._cks: Dict[int, _DeviceCircuit] = {}
+        self._circuits_by_content: Dict[bytes, ConstraintMatrices] = {}   # create_proof_with_reduction: one upload per circuit
 
     # -- handles -------------------------------------------------------------------------
     def _pk(self, pk: ProvingKey, num_inputs: int, shard=(0, 1), dist_h: bool = False) -> _DevicePk:
@@ -284,6 +325,73 @@ class Groth16:
         lb.check(lb.c.g16_generate_parameters(self._ctx.handle, views, ni, matrices.num_constraints, nv, C.byref(tw),
                                               ptr64(_c(g1_generator).reshape(-1)), ptr64(_c(g2_generator).reshape(-1)), C.byref(out)))
         return pk
+
+    # -- generator.rs:20-45 (+ lib.rs:63-74 circuit_specific_setup) -------------------------------
+    def generate_random_parameters_with_reduction(self, circuit, rng=None) -> ProvingKey:
+        """Groth16::generate_random_parameters_with_reduction: synthesise `circuit` in setup mode on the host, draw the toxic
+        waste, random generators (a random multiple of the curve's standard generator, as E::G1::rand does up to distribution)
+        and t outside the domain from `rng`, and build the key on the GPU (generate_parameters_with_qap)."""
+        from .r1cs import synthesize
+
+        cs = synthesize(self.curve, circuit, setup_mode=True)
+        matrices = cs.to_matrices()
+        lb = self._ctx.lib
+        g1s, g2s = _GENERATORS[self.curve]
+        L = FQ_LIMBS[self.curve]
+
+        def rand_generator(g2: bool) -> np.ndarray:
+            k = _rand_fr(self.curve, rng, nonzero=True)   # read as a plain integer below r: any non-zero multiple will do
+            base = _fq_mont(self.curve, [g2s[0][0], g2s[0][1], g2s[1][0], g2s[1][1]] if g2 else list(g1s))
+            out = np.zeros((4 if g2 else 2) * L, dtype=np.uint64)
+            lb.check(lb.c.g16_host_group_op(CURVE_ID[self.curve], int(g2), 1, ptr64(base), ptr64(k), ptr64(out)))
+            return out
+
+        need, n = matrices.num_constraints + matrices.num_instance_variables, 1
+        while n < need:
+            n <<= 1
+        p = _MODULUS_R[self.curve]
+        rinv = pow(1 << 256, -1, p)
+        while True:   # domain.sample_element_outside_domain(rng), generator.rs:90
+            t = _rand_fr(self.curve, rng, nonzero=True)
+            tv = int.from_bytes(t.tobytes(), "little") * rinv % p
+            if pow(tv, n, p) != 1:
+                break
+        alpha, beta, gamma, delta = (_rand_fr(self.curve, rng, nonzero=True) for _ in range(4))
+        return self.generate_parameters_with_qap(matrices, alpha, beta, gamma, delta, rand_generator(False), rand_generator(True), t)
+
+    def setup(self, circuit, rng=None) -> Tuple[ProvingKey, ProvingKey]:
+        """SNARK::circuit_specific_setup (lib.rs:63-74): (pk, vk); the vk is the key's own alpha_g1 / beta_g2 / gamma_g2 / delta_g2
+        / gamma_abc_g1 fields (data_structures.rs:28-41), returned as the same object"""
+        pk = self.generate_random_parameters_with_reduction(circuit, rng)
+        return pk, pk
+
+    # -- prover.rs:173-217 ------------------------------------------------------------------------
+    def create_proof_with_reduction(self, circuit, pk: ProvingKey, r: np.ndarray, s: np.ndarray) -> Proof:
+        """Groth16::create_proof_with_reduction: host-side synthesis exactly as prover.rs:185-204 (fresh constraint system,
+        generate_constraints, matrices, full_assignment = instance ++ witness), then the pure-data call on the GPU.  The
+        device copy of the matrices is cached by content, so proving the same circuit again uploads only the assignment."""
+        import hashlib
+
+        from .r1cs import synthesize
+
+        cs = synthesize(self.curve, circuit, setup_mode=False)
+        m = cs.to_matrices()
+        h = hashlib.sha1()
+        for mat in (m.a, m.b, m.c):
+            for arr in mat:
+                h.update(np.ascontiguousarray(arr).tobytes())
+        h.update(repr((m.num_instance_variables, m.num_witness_variables, m.num_constraints)).encode())
+        m = self._circuits_by_content.setdefault(h.digest(), m)
+        return self.create_proof_with_reduction_and_matrices(pk, r, s, m, cs.num_instance_variables, cs.num_constraints, cs.full_assignment())
+
+    def prove(self, pk: ProvingKey, circuit, rng=None) -> Proof:
+        """SNARK::prove (lib.rs:76-82) = create_random_proof_with_reduction(circuit, pk, rng) (prover.rs:138-150)"""
+        return self.create_proof_with_reduction(circuit, pk, _rand_fr(self.curve, rng), _rand_fr(self.curve, rng))
+
+    def create_proof_no_zk(self, circuit, pk: ProvingKey) -> Proof:
+        """prover.rs:155-168 on a circuit: r = s = 0"""
+        zero = np.zeros(4, dtype=np.uint64)
+        return self.create_proof_with_reduction(circuit, pk, zero, zero)
 
     # -- prover.rs:26-51 -------------------------------------------------------------------
     def create_proof_with_reduction_and_matrices(self, pk: ProvingKey, r: np.ndarray, s: np.ndarray, matrices: ConstraintMatrices,
