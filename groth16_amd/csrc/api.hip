@@ -128,9 +128,12 @@ struct DevicePk {
     // `count` points, row j = 2^(cj) * query.  0 = no tables (plain bases, per-window buckets).  a, b_g1, b_g2 and l share
     // the witness sort and therefore one window size; h has its own.
     int c_z = 0, c_h = 0;
-    // host: multiples of delta_g1 / delta_g2 for the glue of every proof over this key (fixed_base.hpp)
-    FixedBaseTable<typename C::G1X> delta1_tab;
-    FixedBaseTable<typename C::G2X> delta2_tab;
+    // host: multiples of delta_g1 / delta_g2 for the glue of every proof over this key (fixed_base.hpp).  Built by the SECOND
+    // finalize over the key (~35 ms of host work once, ~0.5 ms saved per later proof): a key that proves once never pays.
+    mutable FixedBaseTable<typename C::G1X> delta1_tab;
+    mutable FixedBaseTable<typename C::G2X> delta2_tab;
+    mutable std::mutex tab_mu;
+    mutable int finalize_calls = 0;
 };
 
 struct g16_pk {
@@ -232,11 +235,6 @@ struct Impl {
         p->a_query0 = load_pod<G1A>(v->a_query0);
         p->b_g1_query0 = load_pod<G1A>(v->b_g1_query0);
         p->b_g2_query0 = load_pod<G2A>(v->b_g2_query0);
-        {   // ~35 ms of host work, once per key: the three host threads of every later finalize save ~0.6 ms each
-            auto f1 = std::async(std::launch::async, [&]() { p->delta1_tab.build(G1X::from_affine(p->delta_g1)); });
-            p->delta2_tab.build(G2X::from_affine(p->delta_g2));
-            f1.get();
-        }
         const bool dev = (v->flags & G16_PK_DEVICE_PTRS) != 0;
         int rc = G16_OK;
         // window tables (merged windows, msm.hip): a, b_g1, b_g2 and l share the witness sort, hence one window size
@@ -582,6 +580,14 @@ struct Impl {
         const double t0 = now_ms();
         const FixedPoints fp = {pk->alpha_g1, pk->beta_g1, pk->delta_g1, pk->a_query0, pk->b_g1_query0, pk->beta_g2, pk->delta_g2,
                                 pk->b_g2_query0};
+        {
+            std::lock_guard<std::mutex> lk(pk->tab_mu);
+            if (!pk->delta2_tab.ready() && ++pk->finalize_calls >= 2) {
+                auto f1 = std::async(std::launch::async, [&]() { pk->delta1_tab.build(G1X::from_affine(pk->delta_g1)); });
+                pk->delta2_tab.build(G2X::from_affine(pk->delta_g2));
+                f1.get();
+            }
+        }
         G16_TRY(finalize_core(fp, parts, n_parts, r_, s_, out, &pk->delta1_tab, &pk->delta2_tab));
         const double dt = now_ms() - t0;
         ctx->tm.finish_ms += dt;

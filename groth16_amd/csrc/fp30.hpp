@@ -800,12 +800,35 @@ struct Acc30 {
         }
     }
     G16_HD static Acc30 load_raw(const AccRaw<typename F::Raw>& p) {
-        static_assert(F::LANES_PER_TASK == 1, "raw partials are consumed by one-lane kernels");
-        const F* w = reinterpret_cast<const F*>(&p);
         Acc30 a;
-        a.x = w[0]; a.y = w[1]; a.zz = w[2]; a.zzz = w[3];
-        a.inf = a.zz.raw_zero();
+        if constexpr (F::LANES_PER_TASK == 1) {
+            const F* w = reinterpret_cast<const F*>(&p);
+            a.x = w[0]; a.y = w[1]; a.zz = w[2]; a.zzz = w[3];
+            a.inf = a.zz.raw_zero();
+        } else {   // lane pair: each lane takes the component it owns
+            typedef typename F::B B30;
+            const B30* w = reinterpret_cast<const B30*>(&p);   // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+            const int k = F::lane_hi() ? 1 : 0;
+            a.x.c = w[0 + k]; a.y.c = w[2 + k]; a.zz.c = w[4 + k]; a.zzz.c = w[6 + k];
+            a.inf = F::both(a.zz.c.raw_zero());
+        }
         return a;
+    }
+    // leave the device (pair-aware form of *dst = to_std()): standard-form XYZZ, the identity as all-zero words
+    G16_HD void store_std(XYZZ<StdF>* dst) const {
+        if constexpr (F::LANES_PER_TASK == 1) {
+            *dst = to_std();
+        } else {
+            typedef typename F::B B30;
+            typedef typename B30::Std W;
+            W* w = reinterpret_cast<W*>(dst);
+            const int k = F::lane_hi() ? 1 : 0;
+            const W z = W::zero();
+            w[0 + k] = inf ? z : x.c.to_std();
+            w[2 + k] = inf ? z : y.c.to_std();
+            w[4 + k] = inf ? z : zz.c.to_std();
+            w[6 + k] = inf ? z : zzz.c.to_std();
+        }
     }
     // bucket-kernel output: every lane of the task writes the words it owns
     G16_HD void store_packed(XYZZ<StdF>* dst) const {

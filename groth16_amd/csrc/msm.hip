@@ -451,8 +451,11 @@ template <class P> struct Lazy30<Fp2<P>> {
 #if defined(G16_G2_REDUCE_FP2K30)
     typedef Fp2k30<P> type;       // register-passed Karatsuba (same raw limb layout): less scratch, but one wave per SIMD --
                                   // measured slower for the reductions (82.1 vs 80.8 ms per proof at 2^22, same box)
+#elif defined(G16_G2_REDUCE_FP2X30)
+    typedef Fp2x30<P> type;       // one lane per task, 4-product lazy Fq2 with out-of-line products (2.8 KB of scratch per lane)
 #else
-    typedef Fp2x30<P> type;       // reductions: 4-product lazy Fq2 with out-of-line products
+    typedef Fp2p30<P> type;       // reductions, too, on lane pairs: no scratch, each dependent group operation ~1.7x shorter --
+                                  // what bounds a rank's share of a sharded proof is the G2 reduction chain
 #endif
 #if defined(G16_G2_ACC_FP2X30)
     typedef Fp2x30<P> acc_type;
@@ -471,29 +474,31 @@ template <class P> struct Lazy30<Fp2<P>> {
 static constexpr int HEAVY_THREADS = 128;
 static constexpr int HEAVY_BLOCKS = 512;
 
+// (task = one lane, or one lane pair for the lane-pair Fq2: both lanes of a pair run the same control flow)
 template <class F30>
 __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(AccRaw<typename F30::Raw>* __restrict__ partials, const uint32_t* __restrict__ slot_off,
                                                                      const uint32_t* __restrict__ heavy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
-    const uint32_t nheavy = heavy[0], tid = threadIdx.x;
+    constexpr uint32_t LPT = F30::LANES_PER_TASK, TASKS = HEAVY_THREADS / LPT;
+    const uint32_t nheavy = heavy[0], task = threadIdx.x / LPT;
     for (uint32_t i = blockIdx.x; i < nheavy; i += gridDim.x) {
         const uint32_t b = heavy[1 + i];
         const uint32_t t0 = slot_off[b], t1 = slot_off[b + 1];
         Acc30<F30> acc = Acc30<F30>::identity();
-        for (uint32_t q = t0 + tid; q < t1; q += HEAVY_THREADS) acc.add(Acc30<F30>::load_raw(partials[q]));
+        for (uint32_t q = t0 + task; q < t1; q += TASKS) acc.add(Acc30<F30>::load_raw(partials[q]));
         __syncthreads();  // previous iteration's readers are done with sh / partials[t0]
-        acc.store_raw(&sh[tid]);
+        acc.store_raw(&sh[task]);
         __syncthreads();
-        for (uint32_t d = HEAVY_THREADS / 2; d > 0; d >>= 1) {
-            if (tid < d) {
-                Acc30<F30> x = Acc30<F30>::load_raw(sh[tid]);
-                x.add(Acc30<F30>::load_raw(sh[tid + d]));
-                x.store_raw(&sh[tid]);
+        for (uint32_t d = TASKS / 2; d > 0; d >>= 1) {
+            if (task < d) {
+                Acc30<F30> x = Acc30<F30>::load_raw(sh[task]);
+                x.add(Acc30<F30>::load_raw(sh[task + d]));
+                x.store_raw(&sh[task]);
             }
             __syncthreads();
         }
-        if (tid == 0) partials[t0] = sh[0];
+        if (task == 0) Acc30<F30>::load_raw(sh[0]).store_raw(&partials[t0]);
     }
 }
 
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw
                                                                     const uint32_t* __restrict__ slot_off, uint32_t B, int W, uint32_t G,
                                                                     AccRaw<typename F30::Raw>* __restrict__ chunk_out, AccRaw<typename F30::Raw>* __restrict__ chunk_sum) {
     const uint32_t cpw = B / G;
-    const uint32_t t = blockIdx.x * RED_THREADS + threadIdx.x;
+    const uint32_t t = (blockIdx.x * RED_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
     if (t >= cpw * (uint32_t)W) return;
     const uint32_t w = t / cpw, ch = t % cpw, b_lo = ch * G;
     Acc30<F30> run = Acc30<F30>::identity(), tot = Acc30<F30>::identity();
@@ -531,24 +536,25 @@ __global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw
                                                                     XYZZ<typename F30::Std>* __restrict__ window_sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
-    const uint32_t w = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+    constexpr uint32_t LPT = F30::LANES_PER_TASK, TASKS = WIN_THREADS / LPT;
+    const uint32_t w = blockIdx.x, p = blockIdx.y, task = threadIdx.x / LPT;
     const AccRaw<typename F30::Raw>* src = (p == 0 ? chunk_out : chunk_sum) + (uint64_t)w * cpw;
     const uint32_t mask = p >= 2 ? 1u << (p - 2) : 0u;
     Acc30<F30> acc = Acc30<F30>::identity();
-    for (uint32_t j = tid; j < cpw; j += WIN_THREADS)
+    for (uint32_t j = task; j < cpw; j += TASKS)
         if (!mask || (j & mask)) acc.add(Acc30<F30>::load_raw(src[j]));
-    acc.store_raw(&sh[tid]);
+    acc.store_raw(&sh[task]);
     __syncthreads();
-    for (uint32_t d = WIN_THREADS / 2; d > 0; d >>= 1) {
-        if (tid < d) {
-            Acc30<F30> x = Acc30<F30>::load_raw(sh[tid]);
-            x.add(Acc30<F30>::load_raw(sh[tid + d]));
-            x.store_raw(&sh[tid]);
+    for (uint32_t d = TASKS / 2; d > 0; d >>= 1) {
+        if (task < d) {
+            Acc30<F30> x = Acc30<F30>::load_raw(sh[task]);
+            x.add(Acc30<F30>::load_raw(sh[task + d]));
+            x.store_raw(&sh[task]);
         }
         __syncthreads();
     }
     // the plane sums are what leaves the device: standard arkworks Montgomery radix
-    if (tid == 0) window_sums[(uint64_t)w * gridDim.y + p] = Acc30<F30>::load_raw(sh[0]).to_std();
+    if (task == 0) Acc30<F30>::load_raw(sh[0]).store_std(&window_sums[(uint64_t)w * gridDim.y + p]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -904,7 +910,7 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     const uint32_t cpw = plan.B / G;
     static PerDeviceOnce attr_once;
     bool& attr_set = attr_once.flag();
-    const size_t lds_heavy = sizeof(Raw) * HEAVY_THREADS, lds_win = sizeof(Raw) * WIN_THREADS;
+    const size_t lds_heavy = sizeof(Raw) * HEAVY_THREADS / F30::LANES_PER_TASK, lds_win = sizeof(Raw) * WIN_THREADS / F30::LANES_PER_TASK;
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&heavy_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_heavy));
@@ -917,7 +923,7 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, partials, ss.task_off, ss.heavy);
     G16_LAUNCH_CHECK();
     Raw* chunk_sum = chunk_out + (size_t)cpw * plan.groups;
-    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st,
+    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st,
                        partials, ss.task_off, plan.B, plan.groups, G, chunk_out, chunk_sum);
     G16_LAUNCH_CHECK();
     hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.groups, plan.planes()), dim3(WIN_THREADS), lds_win, st, chunk_out, chunk_sum, cpw,
