@@ -294,6 +294,14 @@ def main():
             dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
             device = torch.device("cpu")  # tensors handed to the collective live on the host for gloo
         dist = dist_mod
+        if backend == "nccl":
+            # the exchange of the distributed witness map is all_to_all_single on int64 [M, 4] device tensors: make sure this RCCL
+            # build carries it (also with one rank, so that the 1-GPU test tier exercises the call the N > 1 runs depend on)
+            probe = torch.arange(4 * 4 * world, dtype=torch.int64, device=device).reshape(4 * world, 4)
+            got = torch.empty_like(probe)
+            dist.all_to_all_single(got, probe)
+            torch.cuda.synchronize()
+            assert world > 1 or bool((got == probe).all()), "RCCL all_to_all_single returned wrong data"
 
     gpu = torch.device(f"cuda:{local_rank}")
 
@@ -391,12 +399,13 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, committed under profiles/);
         # only valid for the workload they were collected on
-        traffic = None
+        traffic, ntt_traffic = None, None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             wl = pt["workload"]
             if wl["curve"] == args.curve and wl["log2_domain"] == args.log2 and wl["n_gpus"] == world:
                 traffic = pt["hbm_bytes_per_launch"]
+                ntt_traffic = pt.get("ntt_hbm_bytes_per_step")
         except Exception:  # noqa: BLE001
             pass
         # the bound that actually applies: v_mad_u64_u32 issue.  One G1 mixed addition = 8 products (338
@@ -417,7 +426,7 @@ def main():
             ntt_bytes = 7 * 2 * 32 * p.n
             roofline_ntt = dict(bound="hbm", achieved=ntt_bytes / (ntt_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, kernel="ntt30_* (7 radix-2 transforms of size n per proof)",
-                                ms_per_step=ntt_ms, algorithmic_bytes_per_step=ntt_bytes, traffic=None,
+                                ms_per_step=ntt_ms, algorithmic_bytes_per_step=ntt_bytes, traffic=ntt_traffic,
                                 note="Fr-product bound in practice (DESIGN.md 4.2); replicated on every rank when sharded")
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload; not measured in this run)" if traffic else None,
