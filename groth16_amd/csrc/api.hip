@@ -241,6 +241,14 @@ struct Impl {
         uint32_t modw[Fr::N];
         for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
         const uint64_t nz = std::max(std::max(v->a.count, v->b_g1.count), std::max(v->b_g2.count, v->l.count));
+        // the one size limit of the MSM path, enforced where the key arrives instead of at the first proof: entry lists are
+        // indexed with 32 bits, a per-window plan has at most 17 windows (c = 16), so a shard of 2^27 points or more of any
+        // query could not be sorted (sort_scalars: n * W < 2^32).  Shard the key further (or over more GPUs) instead.
+        if (std::max(nz, (uint64_t)v->h.count) >= ((uint64_t)1 << 27)) {
+            delete p;
+            g_last_error = "a proving-key shard holds 2^27 or more points of one query: shard it over more ranks";
+            return G16_ERR_BAD_LENGTH;
+        }
         p->c_z = merged_window_bits(nz, Fr::Params::BITS, modw, Fr::N);
         p->c_h = merged_window_bits(v->h.count, Fr::Params::BITS, modw, Fr::N);
         if (v->h.count == 0) p->c_h = p->c_z;

@@ -28,9 +28,15 @@
 
 namespace g16 {
 
-static constexpr int NTT_TILE_LOG = 11;
+// G16_NTT_TILE_LOG = 12 (experiment): 2^12-element tiles, 512 lanes per workgroup, 152 KB of LDS -- one workgroup per CU instead of
+// two; a 2^22-point transform becomes two sweeps (12 + 10 stages) instead of three
+#ifndef G16_NTT_TILE_LOG
+#define G16_NTT_TILE_LOG 11
+#endif
+static constexpr int NTT_TILE_LOG = G16_NTT_TILE_LOG;
 static constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
-static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_THREADS = NTT_TILE_LOG >= 12 ? 512 : 256;
+static constexpr int NTT_MAX_STRIDED = NTT_TILE_LOG >= 12 ? 10 : 8;   // stages per strided pass (runs of 2^(TILE_LOG - k) elements)
 static constexpr int NTT_ROW = NTT_TILE + NTT_TILE / 32;  // padded row length (words) of one limb plane
 
 template <class Fr>
@@ -276,7 +282,7 @@ static std::vector<PassPlan> plan_passes(int log_n) {
     }
     p.push_back({0, NTT_TILE_LOG, 0});
     int rest = log_n - NTT_TILE_LOG;
-    const int npass = (rest + 7) / 8;
+    const int npass = (rest + NTT_MAX_STRIDED - 1) / NTT_MAX_STRIDED;
     int s = NTT_TILE_LOG;
     for (int i = 0; i < npass; ++i) {
         const int left = npass - i;
