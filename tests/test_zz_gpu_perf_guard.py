@@ -1,0 +1,37 @@
+"""Coarse wall-time regression bounds on the MI355X (named to sort LAST: a slow box must not hide the parity results behind -x).
+
+The precise guards are structural and run on the CPU tier (tests/test_kernel_resources.py: registers, occupancy, scratch of the
+built kernels).  These bounds only catch what those cannot see -- a schedule change that serialises the streams, a sort that
+falls off its LDS path -- and are set ~1.6x above the slowest box observed this round (SYN(20), BLS12-381: 24.5-27 ms per proof,
+2.4-2.7 ms per G1 bucket pass)."""
+import os
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_proof_2_20_wall_time_and_bucket_pass():
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = bench.DeviceProver("bls12_381", 20, 1, 0, 1, 0, key="synthetic")
+    for _ in range(3):
+        p.finalize([p.partial()])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g1 = []
+    steps = 6
+    for _ in range(steps):
+        p.finalize([p.partial()])
+        g1 += [x for x in p.timings()["bucket_ms"][:4] if x > 0]
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    assert ms < 42.0, f"SYN(20) proof took {ms:.1f} ms (expected ~25)"
+    assert sum(g1) / len(g1) < 4.2, f"G1 bucket pass {sum(g1) / len(g1):.2f} ms at 2^20 (expected ~2.5)"
