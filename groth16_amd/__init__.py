@@ -12,12 +12,13 @@ Reference interface mirrored (paths relative to /root/reference):
   ProvingKey / Proof / ConstraintMatrices            src/data_structures.rs:8-16,125-143
   SynthesisError.PolynomialDegreeTooLarge            src/r1cs_to_qap.rs:178-179
   Groth16.generate_parameters_with_qap               src/generator.rs:47-208 (matrices form)
+  rerandomize_proof / Groth16.rerandomize_proof      src/prover.rs:223-250 (host: three scalar multiplications)
   Groth16.create_proof_with_reduction / prove / setup src/prover.rs:173-217, src/lib.rs:63-82, src/generator.rs:20-45 -- host-side
       synthesis (groth16_amd.r1cs: ConstraintSystem, Variable, lc, ConstraintSynthesizer) in front of the GPU calls
 """
 from .binding import (G16Error, Lib, PolynomialDegreeTooLarge, SynthesisError, UnexpectedIdentity, lib, FQ_LIMBS, CURVE_ID)  # noqa: F401
 from .groth16 import (ConstraintMatrices, Groth16, LibsnarkReduction, Proof, ProvingKey, ShardedProver, finalize_host,  # noqa: F401
-                      shard_ranges)
+                      rerandomize_proof, shard_ranges)
 from .r1cs import AssignmentMissing, ConstraintSynthesizer, ConstraintSystem, LinearCombination, Variable, lc  # noqa: F401
 
 __all__ = [

@@ -393,6 +393,10 @@ class Groth16:
         zero = np.zeros(4, dtype=np.uint64)
         return self.create_proof_with_reduction(circuit, pk, zero, zero)
 
+    # -- prover.rs:223-250 ----------------------------------------------------------------------
+    def rerandomize_proof(self, vk: ProvingKey, proof: Proof, rng=None) -> Proof:
+        return rerandomize_proof(self.curve, vk, proof, rng)
+
     # -- prover.rs:26-51 -------------------------------------------------------------------
     def create_proof_with_reduction_and_matrices(self, pk: ProvingKey, r: np.ndarray, s: np.ndarray, matrices: ConstraintMatrices,
                                                  num_inputs: int, num_constraints: int, full_assignment: np.ndarray) -> Proof:
@@ -492,6 +496,30 @@ class Groth16:
         lb.check(lb.c.g16_prove_finalize(self._ctx.handle, dpk.handle, arr, len(parts), ptr64(_c(r)), ptr64(_c(s)), C.byref(out)))
         return Proof(np.array(out.a[: 2 * L], dtype=np.uint64), np.array(out.b[: 4 * L], dtype=np.uint64),
                      np.array(out.c[: 2 * L], dtype=np.uint64))
+
+
+def rerandomize_proof(curve: str, vk: "ProvingKey", proof: "Proof", rng=None) -> "Proof":
+    """Groth16::rerandomize_proof (prover.rs:223-250): A' = (1/r1) A, B' = r1 B + r1 r2 delta_g2, C' = C + r2 A for fresh
+    non-zero r1, r2 (figure 1 of BKSV20).  Three scalar multiplications: host work, through the library's host field / group
+    code -- no GPU context needed."""
+    lb, cid, L = lib(), CURVE_ID[curve], FQ_LIMBS[curve]
+    r1, r2 = _rand_fr(curve, rng, nonzero=True), _rand_fr(curve, rng, nonzero=True)
+
+    def fr(op, a, b=None):   # g16_host_field_op on Fr: 2 mul, 3 inverse, 4 to_canonical
+        out = np.zeros(4, dtype=np.uint64)
+        lb.check(lb.c.g16_host_field_op(cid, 0, op, ptr64(_c(a)), ptr64(_c(b)) if b is not None else None, ptr64(out)))
+        return out
+
+    def grp(g2, op, p, q):   # g16_host_group_op: 0 p + q, 1 k * p (k canonical)
+        out = np.zeros((4 if g2 else 2) * L, dtype=np.uint64)
+        lb.check(lb.c.g16_host_group_op(cid, int(g2), op, ptr64(_c(p).reshape(-1)), ptr64(_c(q).reshape(-1)), ptr64(out)))
+        return out
+
+    canon = lambda x: fr(4, x)  # noqa: E731
+    new_a = grp(False, 1, proof.a, canon(fr(3, r1)))
+    new_b = grp(True, 0, grp(True, 1, proof.b, canon(r1)), grp(True, 1, vk.delta_g2, canon(fr(2, r1, r2))))
+    new_c = grp(False, 0, proof.c, grp(False, 1, proof.a, canon(r2)))
+    return Proof(new_a, new_b, new_c)
 
 
 def fixed_points_view(pk: "ProvingKey"):

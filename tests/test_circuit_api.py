@@ -144,6 +144,65 @@ def test_prove_and_verify_my_silly_circuit(curve):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_rerandomize(curve):
+    """src/test.rs:75-118 (test_rerandomize): a rerandomised proof (and its rerandomisation) verifies when the original does,
+    fails on a wrong input, and the three differ as group elements"""
+    import groth16_amd as g
+
+    cp = CP[curve]
+    rng = random.Random(99)
+    with g.Groth16(curve, 0) as prover:
+        pk, vk = prover.setup(MySillyCircuit(), rng)
+        for _ in range(2):
+            a, b = rng.randrange(cp.r), rng.randrange(cp.r)
+            proof1 = prover.prove(pk, MySillyCircuit(a, b), rng)
+            proof2 = prover.rerandomize_proof(vk, proof1, rng)
+            proof3 = prover.rerandomize_proof(vk, proof2, rng)
+            for pr in (proof1, proof2, proof3):
+                assert pm.verify_proof(cp, _vk(cp, vk), _proof(cp, pr), [a * b % cp.r])
+                assert not pm.verify_proof(cp, _vk(cp, vk), _proof(cp, pr), [a])
+            assert not (proof1 == proof2) and not (proof1 == proof3) and not (proof2 == proof3)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_rerandomize_proof_of_an_oracle_proof(orc, curve):
+    """prover.rs:223-250 through the product's host code on a CPU-oracle proof (no GPU): the result verifies, differs from the
+    input, and rerandomising again still verifies (src/test.rs:98-116)"""
+    import groth16_amd as g
+
+    cp = CP[curve]
+    ck = orc.syn_circuit(curve, 4, 21)
+    pk, ex = orc.setup(ck, 2)
+    flat, _ = orc.prove(pk, ck, orc.rand_fr(curve, 3, 1)[0], orc.rand_fr(curve, 4, 1)[0])
+    L = cp.fq_limbs64
+    proof1 = g.Proof(flat[: 2 * L].copy(), flat[2 * L: 6 * L].copy(), flat[6 * L:].copy())
+    vk = g.ProvingKey(curve, pk.alpha_g1, pk.beta_g1, pk.delta_g1, pk.beta_g2, pk.delta_g2, pk.a_query, pk.b_g1_query, pk.b_g2_query,
+                      pk.h_query, pk.l_query, gamma_g2=ex["gamma_g2"], gamma_abc_g1=ex["gamma_abc"])
+    rng = random.Random(5)
+    proof2 = g.rerandomize_proof(curve, vk, proof1, rng)
+    proof3 = g.rerandomize_proof(curve, vk, proof2, rng)
+    public = mont_to_ints(ck.z[1: ck.num_inputs], cp.r)
+    for pr in (proof1, proof2, proof3):
+        assert pm.verify_proof(cp, _vk(cp, vk), _proof(cp, pr), public)
+        assert not pm.verify_proof(cp, _vk(cp, vk), _proof(cp, pr), [(public[0] + 1) % cp.r])
+    assert not (proof1 == proof2) and not (proof2 == proof3) and not (proof1 == proof3)
+
+
+def test_rerandomize_host_math_against_the_model():
+    """the same three formulas in the big-int model on a model proof (no GPU): rerandomised proofs verify"""
+    cp = pm.BN254
+    G1, G2 = pm.groups(cp)
+    cs, z = pm.mimc_circuit(cp, 3, 2)
+    pk, _ = pm.generate_parameters(cp, cs, 5)
+    proof = pm.create_proof_with_reduction_and_matrices(cp, pk, 11, 13, cs, z)
+    r1, r2 = 0x1234567, 0x7654321
+    new = pm.Proof(G1.mul(proof.a, pow(r1, -1, cp.r)), G2.add(G2.mul(proof.b, r1), G2.mul(pk.delta_g2, r1 * r2 % cp.r)),
+                   G1.add(proof.c, G1.mul(proof.a, r2)))
+    assert pm.verify_proof(cp, pk, new, z[1: cs.num_inputs]) and new.a != proof.a
+
+
+@pytest.mark.gpu
 def test_mimc_groth16():
     """tests/mimc.rs:145-229 on BLS12-381 (BASELINE.json configs[0]): parameters from the circuit without values, proofs of
     fresh preimages, verification on the image, rejection of another image"""
