@@ -389,9 +389,8 @@ class Groth16:
         return self.create_proof_with_reduction(circuit, pk, _rand_fr(self.curve, rng), _rand_fr(self.curve, rng))
 
     def create_proof_no_zk(self, circuit, pk: ProvingKey) -> Proof:
-        """prover.rs:155-168 on a circuit: r = s = 0"""
-        zero = np.zeros(4, dtype=np.uint64)
-        return self.create_proof_with_reduction(circuit, pk, zero, zero)
+        """prover.rs:155-168 on a circuit: r = s = 0 (same as create_proof_with_reduction_no_zk(circuit, pk))"""
+        return self.create_proof_with_reduction_no_zk(circuit, pk)
 
     # -- prover.rs:223-250 ----------------------------------------------------------------------
     def rerandomize_proof(self, vk: ProvingKey, proof: Proof, rng=None) -> Proof:
@@ -412,19 +411,27 @@ class Groth16:
                      np.array(out.c[: 2 * L], dtype=np.uint64))
 
     # -- prover.rs:155-168 -----------------------------------------------------------------
-    def create_proof_with_reduction_no_zk(self, pk, matrices, num_inputs, num_constraints, full_assignment) -> Proof:
+    def create_proof_with_reduction_no_zk(self, *args) -> Proof:
+        """the reference's signature ``(circuit, pk)`` (prover.rs:155-168), or the pure-data form
+        ``(pk, matrices, num_inputs, num_constraints, full_assignment)``: r = s = 0"""
         zero = np.zeros(4, dtype=np.uint64)
+        if len(args) == 2 and not isinstance(args[0], ProvingKey):
+            return self.create_proof_with_reduction(args[0], args[1], zero, zero)
+        pk, matrices, num_inputs, num_constraints, full_assignment = args
         return self.create_proof_with_reduction_and_matrices(pk, zero, zero, matrices, num_inputs, num_constraints, full_assignment)
 
     # -- prover.rs:138-150 -----------------------------------------------------------------
-    def create_random_proof_with_reduction(self, pk, matrices, num_inputs, num_constraints, full_assignment, rng=None) -> Proof:
-        p = _MODULUS_R[self.curve]
-
-        def rand():
-            v = (rng.getrandbits(512) if rng is not None else secrets.randbits(512)) % p
-            v = (v << 256) % p  # to Montgomery form
-            return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
-        return self.create_proof_with_reduction_and_matrices(pk, rand(), rand(), matrices, num_inputs, num_constraints, full_assignment)
+    def create_random_proof_with_reduction(self, *args, rng=None) -> Proof:
+        """the reference's signature ``(circuit, pk, rng)`` (prover.rs:138-150), or the pure-data form
+        ``(pk, matrices, num_inputs, num_constraints, full_assignment[, rng])``: fresh r, s from rng"""
+        if not isinstance(args[0], ProvingKey):
+            circuit, pk = args[0], args[1]
+            rng = args[2] if len(args) > 2 else rng
+            return self.create_proof_with_reduction(circuit, pk, _rand_fr(self.curve, rng), _rand_fr(self.curve, rng))
+        pk, matrices, num_inputs, num_constraints, full_assignment = args[:5]
+        rng = args[5] if len(args) > 5 else rng
+        return self.create_proof_with_reduction_and_matrices(pk, _rand_fr(self.curve, rng), _rand_fr(self.curve, rng), matrices, num_inputs,
+                                                             num_constraints, full_assignment)
 
     # -- r1cs_to_qap.rs:172-235 --------------------------------------------------------------
     def witness_map_from_matrices(self, matrices: ConstraintMatrices, num_inputs: int, num_constraints: int,

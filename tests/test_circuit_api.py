@@ -137,8 +137,11 @@ def test_prove_and_verify_my_silly_circuit(curve):
             proof = prover.prove(pk, MySillyCircuit(a, b), rng)
             assert pm.verify_proof(cp, _vk(cp, vk), _proof(cp, proof), [a * b % cp.r])
             assert not pm.verify_proof(cp, _vk(cp, vk), _proof(cp, proof), [a])
-        assert len(prover._cks) == 1            # one upload of the matrices for the three proofs
-        zk = prover.create_proof_no_zk(MySillyCircuit(7, 9), pk)
+        # the reference's own signatures on the reference's own names: (circuit, pk, rng) / (circuit, pk)
+        proof = prover.create_random_proof_with_reduction(MySillyCircuit(3, 4), pk, rng)
+        assert pm.verify_proof(cp, _vk(cp, vk), _proof(cp, proof), [12])
+        assert len(prover._cks) == 1            # one upload of the matrices for all these proofs
+        zk = prover.create_proof_with_reduction_no_zk(MySillyCircuit(7, 9), pk)
         assert zk == prover.create_proof_no_zk(MySillyCircuit(7, 9), pk)      # r = s = 0: deterministic (prover.rs:155-168)
         assert pm.verify_proof(cp, _vk(cp, vk), _proof(cp, zk), [63])
 
