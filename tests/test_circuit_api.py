@@ -223,3 +223,22 @@ def test_mimc_groth16():
             proof = prover.prove(pk, MiMCDemo(xl, xr, constants, cp.r), rng)
             assert pm.verify_proof(cp, _vk(cp, vk), _proof(cp, proof), [image])
             assert not pm.verify_proof(cp, _vk(cp, vk), _proof(cp, proof), [(image + 1) % cp.r])
+
+
+def test_block_distribution_indices_match_the_model():
+    """the product's h_query gather order (dist_h_indices) is the block distribution the modelled distributed witness map leaves
+    h in, and the shards tile [0, n) exactly"""
+    from groth16_amd.groth16 import dist_h_indices
+
+    cp = pm.BN254
+    cs, z = pm.syn_circuit(cp, 6, 3)          # domain 64
+    for N in (2, 4, 8):
+        pieces, idx = pm.distributed_witness_map(cp, cs, z, N)
+        h = pm.witness_map_from_matrices(cp, cs, z)
+        seen = []
+        for r in range(N):
+            mine = dist_h_indices(64, r, N)
+            assert list(mine) == idx[r]
+            assert [h[i] for i in mine] == pieces[r]
+            seen += list(mine)
+        assert sorted(seen) == list(range(64))
