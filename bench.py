@@ -35,8 +35,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import groth16_amd as g  # noqa: E402
-from groth16_amd.binding import (CURVE_ID, FQ_LIMBS, CsrViewC, ParamsViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC, ToxicWasteC,  # noqa: E402
-                                 ptr32, ptr64)
+from groth16_amd.binding import (CURVE_ID, FQ_LIMBS, CsrViewC, DiagC, ParamsViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC,  # noqa: E402
+                                 ToxicWasteC, ptr32, ptr64)
 from groth16_amd.groth16 import _MODULUS_R, DistributedWitnessMap, dist_h_indices  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -257,8 +257,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2", type=int, default=int(os.environ.get("G16_BENCH_LOG2", "22")))
     ap.add_argument("--curve", default="bls12_381")
-    ap.add_argument("--cpu-log2", type=int, default=int(os.environ.get("G16_BENCH_CPU_LOG2", "20")),
-                    help="size of the CPU-baseline sample (2^20: ~10 s of CPU work; pass --cpu-log2 22 for the headline instance itself)")
+    ap.add_argument("--cpu-log2", type=int, default=int(os.environ.get("G16_BENCH_CPU_LOG2", "0")),
+                    help="size of the CPU-baseline sample; default (0) = --log2: the headline instance itself, ONE proof "
+                         "(~25 s of CPU work at 2^22 on 16 cores), which also checks the GPU proof against the CPU prover's bit for bit")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("G16_BENCH_CPU_THREADS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--key", choices=["valid", "synthetic"], default=os.environ.get("G16_BENCH_KEY", "valid"),
@@ -267,6 +268,8 @@ def main():
                     help="DIAGNOSTIC, not a benchmark: time one rank's share of an N-way sharded proof on a single GPU "
                          "(shard 0 of N, no exchange); the JSON line is tagged and must not be read as throughput")
     args = ap.parse_args()
+    if args.cpu_log2 <= 0:
+        args.cpu_log2 = args.log2
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -408,16 +411,22 @@ def main():
                 ntt_traffic = pt.get("ntt_hbm_bytes_per_step")
         except Exception:  # noqa: BLE001
             pass
-        # the bound that actually applies: v_mad_u64_u32 issue.  One G1 mixed addition = 8 products (338
-        # multiply-adds each) + 2 squarings (260); the chip issues at most one v_mad_u64_u32 per ~5 cycles per SIMD
-        # (measured, profiles/r01_ubench.txt): 1024 SIMDs x 64 lanes x 2.4 GHz / 5 = 31.5 T multiply-adds/s.
+        # the bound that actually applies: v_mad_u64_u32 issue.  Both sides of the fraction come from the library
+        # (g16_diag_valu): the multiply-adds of one mixed addition counted from the kernels' own constexpr tables, and the
+        # instruction's issue rate MEASURED on this GPU in this run (all CUs, 8 waves per SIMD, independent chains).
         n_windows = int(last_tm.get("windows", 0))
         valu = None
         if n_windows:
-            mads = float(n_pts) * n_windows * (8 * 338 + 2 * 260 if args.curve == "bls12_381" else 8 * 162 + 2 * 126)
+            dg = DiagC()
+            p.lib.check(p.lib.c.g16_diag_valu(p.ctx, C.byref(dg)))
+            mads = float(n_pts) * n_windows * dg.mads_per_add_g1
             valu = dict(kind="v_mad_u64_u32 issue (integer VALU)", mads_per_launch=mads, achieved_Tmad_s=mads / (avg_ms * 1e-3) / 1e12,
-                        measured_peak_Tmad_s=31.5, frac=mads / (avg_ms * 1e-3) / 31.5e12, window_bits=int(last_tm.get("window_bits", 0)),
-                        windows=n_windows, points_folded_per_launch=n_pts * n_windows)
+                        measured_peak_Tmad_s=dg.mad_per_s / 1e12, frac=mads / (avg_ms * 1e-3) / dg.mad_per_s,
+                        peak_source="g16_diag_valu: mad_rate_kernel timed in this run", mads_per_mixed_add=dg.mads_per_add_g1,
+                        mads_per_field_product=dg.mads_per_product, limbs30=dg.limbs, window_bits=int(last_tm.get("window_bits", 0)),
+                        windows=n_windows, points_folded_per_launch=n_pts * n_windows,
+                        g2=dict(mads_per_mixed_add=dg.mads_per_add_g2, achieved_Tmad_s=float(n_pts) * n_windows * dg.mads_per_add_g2 /
+                                (float(np.mean(bucket_g2)) * 1e-3) / 1e12 if bucket_g2 and np.mean(bucket_g2) > 0 else None))
         # second object for the transforms (2 * 32 * n algorithmic bytes per NTT, seven per proof), from the
         # HIP-event timers around them inside the witness map
         ntt_ms = phase_acc.get("ntt_ms", 0.0) / args.steps
@@ -450,6 +459,10 @@ def main():
                        "parallelism": (f"msm-base-shard x{world}" + (" + distributed witness map (3 all-to-all)" if p.dwm is not None
                                                                              else " (witness map replicated)")) if world > 1 else "single-gpu"},
             "roofline": roofline, "roofline_ntt": roofline_ntt, "value_incl_h2d": h2d,
+            # SURVEY.md 8(d) defines the metric with the witness on the HOST at entry; the bench contract defines `value` with the
+            # inputs resident in HBM.  Both are reported: `value` above (resident), this one with the 32 B x num_variables upload
+            # from pinned host memory inside every timed call.
+            "value_survey_8d": (h2d or {}).get("pinned", {}).get("value"),
             "phases_ms_per_step": {k_: round(v / args.steps, 3) for k_, v in phase_acc.items()},
         }
         if os.environ.get("G16_BENCH_PRINT_PROOF"):

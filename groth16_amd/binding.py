@@ -74,6 +74,11 @@ class PartialC(C.Structure):
                 ("b_g2", C.c_uint64 * 48)]
 
 
+class DiagC(C.Structure):
+    _fields_ = [("mad_per_s", C.c_double), ("mads_per_add_g1", C.c_double), ("mads_per_add_g2", C.c_double),
+                ("mads_per_product", C.c_double), ("limbs", C.c_int)]
+
+
 class TimingsC(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_a_ms", "msm_b_g1_ms", "msm_b_g2_ms", "scalar_prep_ms", "finish_ms",
@@ -88,7 +93,7 @@ class TimingsC(C.Structure):
 EXPORTS = [
     "g16_ctx_create", "g16_ctx_create_multi", "g16_ctx_num_devices", "g16_ctx_destroy", "g16_ctx_stream", "g16_pk_load", "g16_pk_free", "g16_circuit_load", "g16_circuit_free",
     "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_finalize_host", "g16_prove_partial_h", "g16_dwm_create",
-    "g16_dwm_free", "g16_dwm_local_size", "g16_dwm_stage", "g16_get_timings", "g16_witness_map",
+    "g16_dwm_free", "g16_dwm_local_size", "g16_dwm_stage", "g16_get_timings", "g16_diag_valu", "g16_witness_map",
     "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
     "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version", "g16_generate_parameters",
     "g16_host_qap_evaluations", "g16_serialized_point_size", "g16_serialize_points", "g16_deserialize_points",
@@ -149,6 +154,7 @@ class Lib:
         c.g16_prove_finalize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PartialC), C.c_int, u64p, u64p, C.POINTER(ProofC)]
         c.g16_finalize_host.argtypes = [C.c_int, C.POINTER(PkViewC), C.POINTER(PartialC), C.c_int, u64p, u64p, C.POINTER(ProofC)]
         c.g16_get_timings.argtypes = [C.c_void_p, C.POINTER(TimingsC)]
+        c.g16_diag_valu.argtypes = [C.c_void_p, C.POINTER(DiagC)]
         c.g16_witness_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, u64p]
         c.g16_msm_g1.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, u64p]
         c.g16_msm_g2.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, u64p]

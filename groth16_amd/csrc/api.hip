@@ -927,6 +927,23 @@ static bool devices_repeat(const g16_ctx* ctx) {
     return false;
 }
 
+// static multiply-add counts of the bucket kernels' arithmetic, from the tables the kernels themselves are generated from
+template <class B30>
+static void diag_counts(g16_diag* out) {
+    constexpr int NL = B30::NL;
+    int relax1 = 0, relax2 = 0;   // relaxed columns before a second sweep / before the reduction after two sweeps
+    for (int c = 0; c + 1 < 2 * NL; ++c) {
+        if (2 * B30::col_count(c) > G16_RELAX_LIMIT) ++relax1;
+        if (3 * B30::col_count(c) > G16_RELAX_LIMIT) ++relax2;
+    }
+    const double mul = 2.0 * NL * NL + relax1, sqr = NL * (NL + 1) / 2.0 + NL * NL + relax1;
+    const double pair_mul = 3.0 * NL * NL + relax1 + relax2;   // two product sweeps + one reduction per lane
+    out->limbs = NL;
+    out->mads_per_product = mul;
+    out->mads_per_add_g1 = 8 * mul + 2 * sqr;                  // madd-2008-s: U2 S2 PPP Q R(Q-X3) Y1*PPP ZZ*PP ZZZ*PPP + PP, R^2
+    out->mads_per_add_g2 = 2 * (8 * pair_mul + 2 * mul);       // per lane 8 pair products + 2 pair squarings (one product each)
+}
+
 extern "C" {
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
@@ -1343,6 +1360,16 @@ int g16_get_timings(g16_ctx* ctx, g16_timings* out) {
     if (!ctx || !out) return G16_ERR_BAD_ARG;
     *out = ctx->tm;
     return G16_OK;
+}
+
+int g16_diag_valu(g16_ctx* ctx, g16_diag* out) {
+    if (!ctx || !out) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) return g16_diag_valu(ctx->subs[0], out);
+    memset(out, 0, sizeof(*out));
+    if (ctx->curve == G16_BLS12_381) diag_counts<Fp30<Bls12_381::Fq::Params>>(out);
+    else diag_counts<Fp30<Bn254::Fq::Params>>(out);
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    return mad_rate_device(ctx->stream, &out->mad_per_s);
 }
 
 int g16_witness_map(g16_ctx* ctx, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign, int on_device,

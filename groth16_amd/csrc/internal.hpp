@@ -239,6 +239,7 @@ int deserialize_points(int curve, int g2, int compressed, const uint8_t* in, uin
 uint64_t serialized_point_size(int curve, int g2, int compressed);
 
 // ---- synthetic generators (synth.hip) -----------------------------------------------------------
+int mad_rate_device(hipStream_t st, double* mad_per_s);   // measured v_mad_u64_u32 lane-operations per second (diagnostic)
 template <class C> int synth_bases_device(int g2, uint64_t seed, uint64_t first, uint64_t n, void* out_dev, hipStream_t st);
 
 }  // namespace g16

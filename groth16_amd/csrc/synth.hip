@@ -25,6 +25,46 @@ __global__ __launch_bounds__(64) void synth_bases_kernel(Affine<F> gen, uint64_t
     }
 }
 
+// v_mad_u64_u32 issue-rate probe (g16_diag_valu): 8 independent accumulator chains per lane, so the multiplier pipeline is never
+// waiting on a dependent result; 8 waves per SIMD on every CU
+__global__ __launch_bounds__(256) void mad_rate_kernel(uint64_t* __restrict__ out, int iters) {
+    const uint32_t a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 7u;
+    uint64_t r[8];
+    for (int k = 0; k < 8; ++k) r[k] = (uint64_t)a * (uint32_t)(k + 1);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[k]) : "v"(a), "v"(b) : "vcc");
+    }
+    uint64_t acc = 0;
+    for (int k = 0; k < 8; ++k) acc += r[k];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+int mad_rate_device(hipStream_t st, double* mad_per_s) {
+    int dev = 0, cus = 0;
+    G16_HIP_TRY(hipGetDevice(&dev));
+    G16_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int blocks = cus * 8;   // 4 waves per block = one per SIMD; x8 = 8 waves per SIMD
+    const int iters = 8192;
+    uint64_t* d_out = nullptr;
+    G16_HIP_TRY(hipMalloc((void**)&d_out, (size_t)blocks * 256 * sizeof(uint64_t)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = G16_OK;
+    float ms = 0.f;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = G16_ERR_HIP;
+    for (int rep = 0; rc == G16_OK && rep < 2; ++rep) {   // first launch warms the clocks
+        if (hipEventRecord(e0, st) != hipSuccess) { rc = G16_ERR_HIP; break; }
+        hipLaunchKernelGGL(mad_rate_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters);
+        if (hipEventRecord(e1, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = G16_ERR_HIP;
+    }
+    if (rc == G16_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = G16_ERR_HIP;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_out);
+    if (rc == G16_OK) *mad_per_s = (double)blocks * 256.0 * iters * 8.0 / ((double)ms * 1e-3);
+    return rc;
+}
+
 static uint64_t splitmix_next(uint64_t& s) {
     s += 0x9E3779B97F4A7C15ULL;
     uint64_t z = s;

@@ -273,25 +273,24 @@ class Groth16:
         return self._cks[id(m)][1]
 
     def evict_pk(self, pk: ProvingKey, shard=(0, 1)):
-        """drop the device-resident copy of one key shard (its window tables are 13x the shard)"""
-        ent = self._pks.pop((id(pk), shard), None)
-        if ent is not None:
-            ent[1].close()
+        """drop the device-resident copies of one key shard -- the contiguous cut and the block-order cut of the distributed
+        witness map alike (their window tables are 13x the shard)"""
+        for key in ((id(pk), shard), (id(pk), shard, "dist_h")):
+            ent = self._pks.pop(key, None)
+            if ent is not None:
+                ent[1].close()
 
     def evict(self):
-        """drop every cached device-resident key / circuit (frees their HBM)"""
+        """drop every cached device-resident key / circuit (frees their HBM) and the by-content circuit index"""
         for _, p in self._pks.values():
             p.close()
         for _, c in self._cks.values():
             c.close()
         self._pks, self._cks = {}, {}
+        self._circuits_by_content = {}
 
     def close(self):
-        for _, p in self._pks.values():
-            p.close()
-        for _, c in self._cks.values():
-            c.close()
-        self._pks, self._cks = {}, {}
+        self.evict()
         self._ctx.close()
 
     def __enter__(self):
@@ -366,22 +365,40 @@ class Groth16:
         return pk, pk
 
     # -- prover.rs:173-217 ------------------------------------------------------------------------
-    def create_proof_with_reduction(self, circuit, pk: ProvingKey, r: np.ndarray, s: np.ndarray) -> Proof:
+    _MAX_CIRCUITS_BY_CONTENT = 64
+
+    def create_proof_with_reduction(self, circuit, pk: ProvingKey, r: np.ndarray, s: np.ndarray, circuit_id=None) -> Proof:
         """Groth16::create_proof_with_reduction: host-side synthesis exactly as prover.rs:185-204 (fresh constraint system,
         generate_constraints, matrices, full_assignment = instance ++ witness), then the pure-data call on the GPU.  The
-        device copy of the matrices is cached by content, so proving the same circuit again uploads only the assignment."""
+        device copy of the matrices is cached, so proving the same circuit again uploads only the assignment: by
+        `circuit_id` (any hashable the caller vouches for: same id = same constraint matrices; no hashing at all) or, without
+        one, by a SHA-1 of the matrices' content (bounded: the oldest entry and its device copy are dropped past 64 circuits)."""
         import hashlib
 
         from .r1cs import synthesize
 
         cs = synthesize(self.curve, circuit, setup_mode=False)
         m = cs.to_matrices()
-        h = hashlib.sha1()
-        for mat in (m.a, m.b, m.c):
-            for arr in mat:
-                h.update(np.ascontiguousarray(arr).tobytes())
-        h.update(repr((m.num_instance_variables, m.num_witness_variables, m.num_constraints)).encode())
-        m = self._circuits_by_content.setdefault(h.digest(), m)
+        if circuit_id is not None:
+            key = ("id", circuit_id)
+        else:
+            h = hashlib.sha1()
+            for mat in (m.a, m.b, m.c):
+                for arr in mat:
+                    h.update(np.ascontiguousarray(arr).tobytes())
+            h.update(repr((m.num_instance_variables, m.num_witness_variables, m.num_constraints)).encode())
+            key = h.digest()
+        known = self._circuits_by_content.get(key)
+        if known is None:
+            if len(self._circuits_by_content) >= self._MAX_CIRCUITS_BY_CONTENT:
+                old_key = next(iter(self._circuits_by_content))
+                old = self._circuits_by_content.pop(old_key)
+                ent = self._cks.pop(id(old), None)
+                if ent is not None:
+                    ent[1].close()
+            self._circuits_by_content[key] = m
+        else:
+            m = known
         return self.create_proof_with_reduction_and_matrices(pk, r, s, m, cs.num_instance_variables, cs.num_constraints, cs.full_assignment())
 
     def prove(self, pk: ProvingKey, circuit, rng=None) -> Proof:

@@ -192,6 +192,19 @@ int g16_finalize_host(int curve, const g16_pk_view* fixed, const g16_partial* pa
 
 int g16_get_timings(g16_ctx* ctx, g16_timings* out);
 
+/* diagnostics behind bench.py's `roofline.valu_bound` (no reference counterpart): the issue rate of v_mad_u64_u32 -- the
+ * instruction the field products are made of -- measured on this GPU now (all CUs, 8 waves per SIMD, independent chains), and
+ * the multiply-adds one mixed addition of the G1 / G2 bucket kernels executes, counted from the same constexpr tables the
+ * kernels are generated from (limb count, relaxed columns) */
+typedef struct {
+    double mad_per_s;          /* measured: v_mad_u64_u32 lane-operations per second, whole GPU                  */
+    double mads_per_add_g1;    /* static: multiply-adds per G1 mixed addition (8 products + 2 squarings)           */
+    double mads_per_add_g2;    /* static: per G2 mixed addition, both lanes of the pair together                   */
+    double mads_per_product;   /* static: one base-field product (limb products + Montgomery reduction + relaxation) */
+    int limbs;                 /* 30-bit limbs of the base field                                                   */
+} g16_diag;
+int g16_diag_valu(g16_ctx* ctx, g16_diag* out);
+
 /* ---- unit-level entry points (parity tests, micro-benchmarks) ---- */
 
 /* h_out: domain_size Fr, natural order */

@@ -60,8 +60,9 @@ def run_all_ranks(g, prover, gm, z, world):
 
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("k,world", [(2, 2), (4, 2), (4, 4), (6, 8), (10, 2), (10, 4), (10, 8), (12, 16), (16, 8)])
+@pytest.mark.parametrize("k,world", [(2, 2), (4, 2), (4, 4), (6, 8), (10, 2), (10, 4), (10, 8), (12, 16), (16, 8), (20, 8), (22, 8)])
 def test_distributed_witness_map_matches_oracle(g, orc, curve, k, world):
+    """k = 20, 22: BASELINE.json's sizes -- the local transforms are multi-sweep (2^17 / 2^19-point domains) only there"""
     ck = orc.syn_circuit(curve, k, 70 + k + world)
     with g.Groth16(curve, 0) as prover:
         ranks, h = run_all_ranks(g, prover, mats_of(g, ck), ck.z, world)

@@ -98,7 +98,7 @@ def oracle_parts(cp, parts):
     return [arr_to_g1(parts[2 * L * i: 2 * L * (i + 1)], cp)[0] for i in range(4)] + [arr_to_g2(parts[8 * L: 12 * L], cp)[0]]
 
 
-@pytest.mark.parametrize("curve,k,full_oracle", [("bls12_381", 20, True), ("bn254", 20, True), ("bls12_381", 22, False), ("bn254", 22, False)],
+@pytest.mark.parametrize("curve,k,full_oracle", [("bls12_381", 20, True), ("bn254", 20, True), ("bls12_381", 22, True), ("bn254", 22, True)],
                          ids=["bls12_381-k20", "bn254-k20", "bls12_381-k22", "bn254-k22"])
 def test_full_size_proof_bit_exact(g, orc, curve, k, full_oracle):
     cp = CP[curve]
@@ -199,5 +199,38 @@ def test_sharded_2_24_three_shards_trapdoor(g, orc):
         h_gpu = prover.witness_map_from_matrices(mats, ck.num_inputs, ck.num_constraints, ck.z)
     h_orc = orc.witness_map(ck)
     assert (h_gpu == h_orc).all()
+    ex = trapdoor_extras(g, curve, ck, toxic, gens["g1gen"], gens["g2gen"])
+    assert (proof.flat() == orc.trapdoor_proof(ck, ex, h_orc, r, s)).all()
+
+
+def test_configs4_2_24_eight_ranks_distributed_map_block_h(g, orc):
+    """BASELINE.json configs[4] AS SPECIFIED, every rank on the one visible GPU: 2^24 constraints, BLS12-381, world = 8.
+    Distributed witness map (four stages per rank, the three all-to-all exchanges done by moving the chunks between the
+    ranks' buffers) -> per rank g16_prove_partial_h over ITS key shard, whose h_query is gathered in the block order the map
+    leaves h in (load 16 GB of window tables, prove, evict) -> g16_prove_finalize over the eight records.  What must not depend
+    on the cut: h of src/r1cs_to_qap.rs:232 (all 2^24 coefficients against the oracle's) and the five sums of
+    src/prover.rs:66,74,92,105,113 (the proof against the trapdoor closed form)."""
+    from test_gpu_dist_wm import run_all_ranks
+
+    curve, k, world = "bls12_381", 24, 8
+    ck = orc.syn_circuit(curve, k, 4)
+    toxic = orc.rand_fr(curve, 1924, 5)
+    gens = orc.setup(orc.syn_circuit(curve, 2, 1), 3)[1]
+    r, s = orc.rand_fr(curve, 91, 1)[0], orc.rand_fr(curve, 92, 1)[0]
+    with g.Groth16(curve, 0) as prover:
+        mats = mats_of(g, ck)
+        pk = prover.generate_parameters_with_qap(mats, toxic[0], toxic[1], toxic[2], toxic[3], gens["g1gen"], gens["g2gen"], toxic[4])
+        ranks, h_gpu = run_all_ranks(g, prover, mats, ck.z, world)
+        parts = []
+        for d in ranks:
+            parts.append(prover.prove_partial_h(pk, mats, ck.z, (d.rank, world), d.h_local.data_ptr(), d.M))
+            if d.rank < world - 1:
+                prover.evict_pk(pk, (d.rank, world))
+        proof = prover.prove_finalize(pk, ck.num_inputs, parts, r, s, (world - 1, world), dist_h=True)
+        for d in ranks:
+            d.close()
+    h_orc = orc.witness_map(ck)
+    assert (h_gpu == h_orc).all()
+    assert not h_gpu[-1].any()
     ex = trapdoor_extras(g, curve, ck, toxic, gens["g1gen"], gens["g2gen"])
     assert (proof.flat() == orc.trapdoor_proof(ck, ex, h_orc, r, s)).all()
