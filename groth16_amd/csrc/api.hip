@@ -871,10 +871,12 @@ static void g16_dwm_free_impl(g16_dwm* d) {
     d->dw = nullptr;
 }
 
-// run fn(i) for i < n on n host threads; first non-zero status wins.  serial = true runs them one after the other on the
-// calling thread (the LOAD paths of a context that lists one physical device several times: n concurrent table builds on one
-// GPU buy nothing, and their 9-17 KB/lane scratch demands on sibling queues of one device have aborted inside the HIP runtime
-// in the full test suite -- never in isolation)
+// run fn(i) for i < n on n host threads.  Status: the first REAL failure by device index -- a thread that only gave up because
+// a sibling failed returns SIBLING_FAILED, which never masks the sibling's own code -- and that thread's error text becomes the
+// caller's g16_last_error() (g_last_error is thread_local).  Every thread is created before any of them runs fn (a start gate):
+// if thread creation fails part-way nobody has entered a barrier that expects n participants.
+// serial = true runs them one after the other on the calling thread.
+static constexpr int SIBLING_FAILED = -1;
 template <class Fn>
 static int for_each_device(int n, Fn fn, bool serial = false) {
     if (serial) {
@@ -885,16 +887,38 @@ static int for_each_device(int n, Fn fn, bool serial = false) {
         return G16_OK;
     }
     std::vector<int> rc((size_t)n, G16_OK);
+    std::vector<std::string> msg((size_t)n);
+    std::mutex mu;
+    std::condition_variable cv;
+    int gate = 0;   // 0: wait, 1: go, -1: abort
+    auto body = [&](int i) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return gate != 0; });
+            if (gate < 0) return;
+        }
+        rc[(size_t)i] = fn(i);
+        if (rc[(size_t)i]) msg[(size_t)i] = g_last_error;
+    };
     std::vector<std::thread> th;
     try {
-        for (int i = 1; i < n; ++i) th.emplace_back([&, i]() { rc[(size_t)i] = fn(i); });
+        for (int i = 1; i < n; ++i) th.emplace_back(body, i);
     } catch (...) {
+        { std::lock_guard<std::mutex> lk(mu); gate = -1; }
+        cv.notify_all();
         for (auto& t : th) t.join();
+        g_last_error = "could not start one host thread per device";
         return G16_ERR_INTERNAL;
     }
+    { std::lock_guard<std::mutex> lk(mu); gate = 1; }
+    cv.notify_all();
     rc[0] = fn(0);
+    if (rc[0]) msg[0] = g_last_error;
     for (auto& t : th) t.join();
-    for (int v : rc) if (v) return v;
+    int pick = -1;
+    for (int i = 0; i < n && pick < 0; ++i) if (rc[(size_t)i] != G16_OK && rc[(size_t)i] != SIBLING_FAILED) pick = i;
+    if (pick >= 0) { g_last_error = msg[(size_t)pick]; return rc[(size_t)pick]; }
+    for (int v : rc) if (v) return G16_ERR_INTERNAL;   // only markers: cannot happen (a marker needs a failed sibling)
     return G16_OK;
 }
 
@@ -1277,7 +1301,7 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                     });
                 }
                 if (i == 0) dwm_ms = now_ms() - tw;
-                if (failed.load() || my) return my ? my : G16_ERR_INTERNAL;
+                if (failed.load() || my) return my ? my : SIBLING_FAILED;
                 return g16_prove_partial_h(sub, pk->subs[(size_t)i], circuit->subs[(size_t)i], zp, n_assign, 1, sl.h_local, M, skip_b_g1,
                                            &parts[(size_t)i]);
             });

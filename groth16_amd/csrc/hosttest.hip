@@ -3,10 +3,31 @@
 #include "internal.hpp"
 #include "fp30.hpp"
 #include "batch_affine.hpp"
+#include "window_tables.hpp"
 #include "fixed_base.hpp"
 #include <vector>
 
 using namespace g16;
+
+namespace g16 {
+// Host emulation of the Fp2p30 lane pair: both lanes' components in one object, every product through the pair's own pure
+// per-lane routines (pair_mul / pair_sqr / pair_inverse with hi = false and hi = true) -- what the two lanes of the G2 window-table
+// task compute, without a wave.
+template <class P>
+struct Fp2e30 {
+    typedef Fp30<P> B;
+    typedef Fp2p30<P> PP;
+    B c0, c1;
+    static Fp2e30 one() { return {B::one(), B::zero()}; }
+    Fp2e30 add(const Fp2e30& o) const { return {c0.add(o.c0), c1.add(o.c1)}; }
+    Fp2e30 dbl() const { return {c0.dbl(), c1.dbl()}; }
+    template <int K> Fp2e30 sub(const Fp2e30& o) const { return {c0.template sub<K>(o.c0), c1.template sub<K>(o.c1)}; }
+    Fp2e30 mul(const Fp2e30& o) const { return {PP::pair_mul(false, c0, c1, o.c0, o.c1), PP::pair_mul(true, c1, c0, o.c1, o.c0)}; }
+    Fp2e30 sqr() const { return {PP::pair_sqr(false, c0, c1), PP::pair_sqr(true, c1, c0)}; }
+};
+template <class P>
+Fp2e30<P> batch_inverse(const Fp2e30<P>& a) { return {pair_inverse<P>(false, a.c0, a.c1), pair_inverse<P>(true, a.c1, a.c0)}; }
+}  // namespace g16
 
 namespace {
 
@@ -237,6 +258,86 @@ struct SelfTest {
         return 0;
     }
 
+    // ---------------------------------------------------------------------------------------
+    // window tables (window_tables.hpp): the task's arithmetic -- Jacobian doublings in the lazy field, parked rows, ONE
+    // inversion, canonical affine rows -- against c * j plain XYZZ doublings + to_affine of the standard code.  G1 on Fp30,
+    // G2 on the two-component emulation of the lane pair.
+    template <class E>
+    struct TableHostIO {
+        typedef E F;
+        bool ident;
+        F x0, y0;
+        std::vector<F> park;
+        std::vector<F> rx, ry;
+        std::vector<int> rid;    // 1 = identity row, 0 = finite, -1 = never written
+        bool load(F& x, F& y) const { if (ident) return false; x = x0; y = y0; return true; }
+        void store(int row, const F& x, const F& y) { rx[row] = x; ry[row] = y; rid[row] = 0; }
+        void store_identity(int row) { rid[row] = 1; }
+        void put(int slot, const F& v) { park[slot] = v; }
+        F get(int slot) const { return park[slot]; }
+        static bool zero1(const F30& v) { return v.maybe_zero() && v.is_zero_exact(); }
+        static bool is_zero_impl(const F30& v) { return zero1(v); }
+        static bool is_zero_impl(const Fp2e30<typename Fq::Params>& v) { return zero1(v.c0) && zero1(v.c1); }
+        bool is_zero(const F& v) const { return is_zero_impl(v); }
+        static F30 canon_impl(const F30& v) { return v.canonical_lt2p(); }
+        static Fp2e30<typename Fq::Params> canon_impl(const Fp2e30<typename Fq::Params>& v) { return {v.c0.canonical_lt2p(), v.c1.canonical_lt2p()}; }
+        F canonical(const F& v) const { return canon_impl(v); }
+    };
+    static bool same30(const F30& a, const Fq& std_val) {   // lazy canonical limbs == canonical x R' of the standard value
+        Fq got;
+        a.pack(got.v);
+        return got == F30::std_to_r30(std_val);
+    }
+    static int selftest_window_table(uint64_t seed) {
+        typedef Fp2e30<typename Fq::Params> E2;
+        uint64_t st = seed ^ 0x7AB1E;
+        const int cases[4][2] = {{3, 1}, {5, 4}, {20, 13}, {19, 14}};   // (c, W)
+        for (int cs = 0; cs < 4; ++cs) {
+            const int c = cases[cs][0], W = cases[cs][1];
+            for (int it = 0; it < 3; ++it) {
+                uint32_t k[2] = {(uint32_t)sm_next(st) | 1u, (uint32_t)sm_next(st)};
+                {   // G1
+                    const G1A p = it == 2 ? G1A::identity() : G1X::from_affine(C::g1_generator()).mul_bits(k, 64).to_affine();
+                    TableHostIO<F30> io;
+                    io.ident = p.is_identity();
+                    io.x0 = to30(p.x); io.y0 = to30(p.y);
+                    io.park.assign((size_t)4 * W, F30::zero());
+                    io.rx.assign(W, F30::zero()); io.ry.assign(W, F30::zero()); io.rid.assign(W, -1);
+                    window_table_task<F30>(io, c, W);
+                    G1X ref = G1X::from_affine(p);
+                    for (int j = 0; j < W; ++j) {
+                        if (j) for (int d = 0; d < c; ++d) ref = ref.dbl();
+                        const G1A a = ref.to_affine();
+                        if (io.rid[j] < 0) return 700;
+                        if (a.is_identity() != (io.rid[j] == 1)) return 701;
+                        if (!a.is_identity() && (!same30(io.rx[j], a.x) || !same30(io.ry[j], a.y))) return 702;
+                    }
+                }
+                {   // G2, lane-pair emulation
+                    const G2A p = it == 2 ? G2A::identity() : G2X::from_affine(C::g2_generator()).mul_bits(k, 64).to_affine();
+                    TableHostIO<E2> io;
+                    io.ident = p.is_identity();
+                    io.x0 = E2{to30(p.x.c0), to30(p.x.c1)}; io.y0 = E2{to30(p.y.c0), to30(p.y.c1)};
+                    const E2 z2 = {F30::zero(), F30::zero()};
+                    io.park.assign((size_t)4 * W, z2);
+                    io.rx.assign(W, z2); io.ry.assign(W, z2); io.rid.assign(W, -1);
+                    window_table_task<E2>(io, c, W);
+                    G2X ref = G2X::from_affine(p);
+                    for (int j = 0; j < W; ++j) {
+                        if (j) for (int d = 0; d < c; ++d) ref = ref.dbl();
+                        const G2A a = ref.to_affine();
+                        if (io.rid[j] < 0) return 710;
+                        if (a.is_identity() != (io.rid[j] == 1)) return 711;
+                        if (!a.is_identity() && (!same30(io.rx[j].c0, a.x.c0) || !same30(io.rx[j].c1, a.x.c1) || !same30(io.ry[j].c0, a.y.c0) ||
+                                                 !same30(io.ry[j].c1, a.y.c1)))
+                            return 712;
+                    }
+                }
+            }
+        }
+        return 0;
+    }
+
     static int selftest30(uint64_t seed, int iters) {
         uint64_t st = seed;
         {
@@ -253,6 +354,10 @@ struct SelfTest {
         }
         {
             const int rc = selftest_affine(seed, iters);
+            if (rc) return rc;
+        }
+        {
+            const int rc = selftest_window_table(seed);
             if (rc) return rc;
         }
         for (int it = 0; it < iters; ++it) {

@@ -1,6 +1,7 @@
 // Internal plumbing shared by the translation units of libg16_mi355x.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -30,10 +31,11 @@ void set_last_error(const char* what, hipError_t e, const char* file, int line);
 
 #define G16_LAUNCH_CHECK() G16_HIP_TRY(hipGetLastError())
 
-// hipFuncSetAttribute is per device: one "already raised the dynamic-LDS limit" flag per (call site, device)
+// hipFuncSetAttribute is per device: one "already raised the dynamic-LDS limit" flag per (call site, device).  Atomic: the
+// per-device host threads of a multi-device context reach the same call site concurrently (a lost race only repeats the call).
 struct PerDeviceOnce {
-    bool done[64] = {};
-    bool& flag() {
+    std::atomic<bool> done[64] = {};
+    std::atomic<bool>& flag() {
         int dev = 0;
         (void)hipGetDevice(&dev);
         return done[dev & 63];

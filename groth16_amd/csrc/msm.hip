@@ -43,6 +43,7 @@
 #include "msm_common.hpp"
 #include "fp30.hpp"
 #include "batch_affine.hpp"
+#include "window_tables.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -764,7 +765,7 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     for (int k = 0; k < 10; ++k) pd.K[k] = plan.K[k];
     const size_t lds = (size_t)plan.B * sizeof(uint32_t);
     static PerDeviceOnce attr_once;
-    bool& attr_set = attr_once.flag();
+    std::atomic<bool>& attr_set = attr_once.flag();
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         128 * 1024));
@@ -909,7 +910,7 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
     static PerDeviceOnce attr_once;
-    bool& attr_set = attr_once.flag();
+    std::atomic<bool>& attr_set = attr_once.flag();
     const size_t lds_heavy = sizeof(Raw) * HEAVY_THREADS / F30::LANES_PER_TASK, lds_win = sizeof(Raw) * WIN_THREADS / F30::LANES_PER_TASK;
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&heavy_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -971,48 +972,48 @@ XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
     return total;
 }
 
-// table[j * n + i] = 2^(c j) P_i.  One lane per point: W-1 runs of c doublings in XYZZ, ONE field inversion for all of
-// them (Montgomery's trick over the ZZ*ZZZ products), output in the bucket kernel's radix.  Runs once per key.
+// table[j * n + i] = 2^(c j) P_i (window_tables.hpp): one lane (G1) or one lane pair (G2) per point in the 30-bit lazy arithmetic,
+// Jacobian doublings, ONE field inversion per point; the rows' (X, Y, Z, prefix product) wait for the backward sweep in `park`,
+// a limb-planar HBM buffer of 4 (W - 1) NL words per lane.  Runs once per key, in chunks of TABLE_CHUNK points.
 static constexpr int TABLE_MAX_W = 32;
-template <class F>
-__global__ __launch_bounds__(64) void build_window_tables_kernel(const Affine<F>* __restrict__ src, uint64_t n, int c, int W,
-                                                                  Affine<F>* __restrict__ table) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Affine<F> p = src[i];
-    Affine<F> o;
-    o.x = to_r30(p.x); o.y = to_r30(p.y);
-    table[i] = o;
-    XYZZ<F> pt[TABLE_MAX_W];
-    F pre[TABLE_MAX_W];
-    XYZZ<F> acc = XYZZ<F>::from_affine(p);
-    F run = F::one();
-    for (int j = 1; j < W; ++j) {
-        for (int k = 0; k < c; ++k) acc = acc.dbl();
-        pt[j] = acc;
-        pre[j] = run;                                  // product of the t's before j
-        if (!acc.is_identity()) run = run * (acc.zz * acc.zzz);
-    }
-    F inv = run.inverse();                             // run != 0: a product of non-zero ZZ*ZZZ (or one)
-    for (int j = W - 1; j >= 1; --j) {
-        Affine<F> a = Affine<F>::identity();
-        if (!pt[j].is_identity()) {
-            const F it = inv * pre[j];                 // 1 / (ZZ ZZZ)
-            inv = inv * (pt[j].zz * pt[j].zzz);
-            a.x = to_r30(pt[j].x * (it * pt[j].zzz));  // X / ZZ
-            a.y = to_r30(pt[j].y * (it * pt[j].zz));   // Y / ZZZ
-        }
-        table[(uint64_t)j * n + i] = a;
-    }
+static constexpr int TABLE_THREADS = 128;
+static constexpr uint64_t TABLE_CHUNK = (uint64_t)1 << 18;   // points per launch: 2^18 (G1) / 2^19 (G2) lanes, park <= 1.3 GB
+template <class F30>
+__global__ __launch_bounds__(TABLE_THREADS, 2) void build_window_tables_kernel(const Affine<typename F30::Std>* __restrict__ src, uint64_t first,
+                                                                              uint64_t count, uint64_t n, int c, int W,
+                                                                              Affine<typename F30::Std>* __restrict__ table, uint32_t* __restrict__ park) {
+    typedef TableDeviceIO<F30> IO;
+    typedef typename IO::W32 W32;
+    const uint64_t lane = (uint64_t)blockIdx.x * TABLE_THREADS + threadIdx.x;
+    const uint64_t t = lane / F30::LANES_PER_TASK;   // lanes of one task are adjacent
+    if (t >= count) return;
+    const uint64_t i = first + t;
+    IO io{reinterpret_cast<const W32*>(src + i), reinterpret_cast<W32*>(table + i), n * 2 * IO::TL::PARTS, park + lane, count * F30::LANES_PER_TASK};
+    window_table_task<F30>(io, c, W);
 }
 
 template <class F>
 int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine<F>* d_table, hipStream_t st) {
+    typedef typename Lazy30<F>::acc_type F30;
+    static_assert(sizeof(Affine<F>) == 2 * TableLane<F30>::PARTS * sizeof(typename TableLane<F30>::B::Std), "affine point = x parts | y parts");
     if (n == 0) return G16_OK;
     if (W > TABLE_MAX_W) return G16_ERR_INTERNAL;
-    hipLaunchKernelGGL((build_window_tables_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_src, n, c, W, d_table);
-    G16_LAUNCH_CHECK();
-    return G16_OK;
+    const uint64_t chunk = std::min(n, TABLE_CHUNK);
+    const size_t park_words = (size_t)4 * (W > 1 ? W - 1 : 1) * TableLane<F30>::B::NL * chunk * F30::LANES_PER_TASK;
+    uint32_t* park = nullptr;
+    if (hipMalloc((void**)&park, park_words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return G16_ERR_OOM; }
+    int rc = G16_OK;
+    for (uint64_t first = 0; first < n && rc == G16_OK; first += chunk) {
+        const uint64_t count = std::min(chunk, n - first);
+        const uint64_t lanes = count * F30::LANES_PER_TASK;
+        hipLaunchKernelGGL((build_window_tables_kernel<F30>), dim3((unsigned)((lanes + TABLE_THREADS - 1) / TABLE_THREADS)), dim3(TABLE_THREADS), 0, st,
+                           d_src, first, count, n, c, W, d_table, park);
+        if (hipGetLastError() != hipSuccess) rc = G16_ERR_HIP;
+    }
+    // the parking buffer is load-time scratch: wait for the chunks and give it back (g16_pk_load is synchronous anyway)
+    if (hipStreamSynchronize(st) != hipSuccess && rc == G16_OK) rc = G16_ERR_HIP;
+    (void)hipFree(park);
+    return rc;
 }
 
 #define G16_INSTANTIATE_MSM(C)                                                                                               \

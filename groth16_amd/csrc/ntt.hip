@@ -302,7 +302,7 @@ static int launch_pass(Fp<P>* data, const Fp<P>* tw, const Fp<P>* prescale, int 
     const size_t blocks = ((size_t)1 << log_n) / E;
     const size_t lds_bytes = (size_t)Fp30<P>::NL * NTT_ROW * sizeof(uint32_t);
     static PerDeviceOnce attr_once;
-    bool& attr_set = attr_once.flag();
+    std::atomic<bool>& attr_set = attr_once.flag();
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt30_pass_kernel<P, DIT>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -355,7 +355,7 @@ int ntt_dif_dit(const Domain<C>* d, typename C::Fr* data, bool dif_inverse, cons
         const size_t blocks = ((size_t)1 << d->log_n) >> K;
         const size_t lds_bytes = (size_t)Fp30<P>::NL * NTT_ROW * sizeof(uint32_t);
         static PerDeviceOnce attr_once;
-        bool& attr_set = attr_once.flag();
+        std::atomic<bool>& attr_set = attr_once.flag();
         if (!attr_set) {
             G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt30_dif_dit_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes));

@@ -18,7 +18,8 @@
 
 namespace g16 {
 
-// (X, Y, Z) <- 2 (X, Y, Z) on y^2 = x^3 + b, lazy bounds: in X, Y < 5.5p, Z < 3p (an affine start: < p, < p, one); out the same.
+// (X, Y, Z) <- 2 (X, Y, Z) on y^2 = x^3 + b, lazy bounds per base-field component: in X < 5.8p, Y < 5.5p, Z < 3p (an affine
+// start: < p, < p, one); out the same.
 //   A = X^2, B = Y^2, D = X * 4B (= 4 X Y^2), E = 3A, X3 = E^2 - 2D, Y3 = E (D - X3) - 8 B^2, Z3 = 2 Y Z
 template <class F>
 G16_HD void jac30_double(F& X, F& Y, F& Z) {
@@ -34,88 +35,116 @@ G16_HD void jac30_double(F& X, F& Y, F& Z) {
     Z = Z3;
 }
 
-template <class F30> struct TableLane;   // what one lane of a task holds of a field value, and how it reaches memory
+// The arithmetic of one task (= one point): rows 1 .. W - 1 of its window table.  F is the lazy field as the task's lane(s)
+// hold it (Fp30 for G1, the lane-pair Fp2p30 for G2; the host self-test runs a two-component emulation of the pair); IO is
+// where the task's data lives:
+//   bool load(F& x, F& y)            the point in the R' radix, canonical; false for the identity
+//   void store(int row, x, y)        canonical affine coordinates of a row (row 0 included)
+//   void store_identity(int row)
+//   void put(int slot, v) / F get(int slot)     4 (W - 1) parking slots
+//   bool is_zero(v)                  exact test of a lazy value (< 16p per component), uniform over the task's lanes
+//   F canonical(v)                   lazy (< 2p per component) -> [0, p)
+template <class F, class IO>
+G16_HD void window_table_task(IO& io, int c, int W) {
+    F X, Y;
+    if (!io.load(X, Y)) {
+        for (int j = 0; j < W; ++j) io.store_identity(j);
+        return;
+    }
+    io.store(0, X, Y);
+    F Z = F::one(), run = F::one();
+    // forward: rows 1 .. live - 1 are finite; a point of 2-power order (never a subgroup point of these curves, but the caller's
+    // bases are not checked) reaches the identity at some row, from which on every row is the identity
+    int live = W;
+    for (int j = 1; j < W; ++j) {
+        for (int d = 0; d < c; ++d) jac30_double(X, Y, Z);
+        if (io.is_zero(Z)) { live = j; break; }
+        io.put(4 * (j - 1) + 0, X);
+        io.put(4 * (j - 1) + 1, Y);
+        io.put(4 * (j - 1) + 2, Z);
+        io.put(4 * (j - 1) + 3, run);   // product of the Z's of rows 1 .. j - 1
+        run = run.mul(Z);
+    }
+    F inv = batch_inverse(run);          // run != 0: a product of non-zero Z's (or one)
+    for (int j = W - 1; j >= live; --j) io.store_identity(j);
+    for (int j = live - 1; j >= 1; --j) {
+        const F Zj = io.get(4 * (j - 1) + 2);
+        const F zi = inv.mul(io.get(4 * (j - 1) + 3));   // 1 / Z_j
+        inv = inv.mul(Zj);
+        const F zi2 = zi.sqr();
+        const F ax = io.get(4 * (j - 1) + 0).mul(zi2);              // X / Z^2
+        const F ay = io.get(4 * (j - 1) + 1).mul(zi2.mul(zi));      // Y / Z^3
+        io.store(j, io.canonical(ax), io.canonical(ay));
+    }
+}
+
+// ---- device side: where a lane of the task finds its share of the data ----------------------------------------------------
+template <class F30> struct TableLane;   // what one lane of a task holds of a field value
 template <class P>
 struct TableLane<Fp30<P>> {
-    typedef Fp30<P> F30;
     typedef Fp30<P> B;
-    G16_HD static const B& comp(const F30& v) { return v; }
-    G16_HD static F30 wrap(const B& b) { return b; }
+    G16_HD static const B& comp(const Fp30<P>& v) { return v; }
+    G16_HD static Fp30<P> wrap(const B& b) { return b; }
     G16_HD static bool all(bool v) { return v; }
     G16_HD static int part() { return 0; }                      // which Fq of an affine coordinate this lane owns
     static constexpr int PARTS = 1;                             // base-field elements per coordinate
 };
 template <class P>
 struct TableLane<Fp2p30<P>> {
-    typedef Fp2p30<P> F30;
     typedef Fp30<P> B;
-    G16_HD static const B& comp(const F30& v) { return v.c; }
-    G16_HD static F30 wrap(const B& b) { return F30{b}; }
-    G16_HD static bool all(bool v) { return F30::both(v); }
-    G16_HD static int part() { return F30::lane_hi() ? 1 : 0; }
+    G16_HD static const B& comp(const Fp2p30<P>& v) { return v.c; }
+    G16_HD static Fp2p30<P> wrap(const B& b) { return Fp2p30<P>{b}; }
+    G16_HD static bool all(bool v) { return Fp2p30<P>::both(v); }
+    G16_HD static int part() { return Fp2p30<P>::lane_hi() ? 1 : 0; }
     static constexpr int PARTS = 2;
 };
 
-// One task = one point: rows 1 .. W - 1 of its window table.  `park` is the task-private view of the HBM scratch: slot s, limb l
-// of this lane at park[(s * NL + l) * stride]; 4 (W - 1) slots.  src / table are arrays of base-field elements:
-// a point is 2 * PARTS of them (x parts, then y parts), this lane reads / writes element `part` of each coordinate.
-// Returns nothing; row 0 (the point itself, converted to the R' radix) is written here too.
+// src / table: arrays of packed base-field elements, a point = 2 * PARTS of them (x parts, then y parts); this lane reads / writes
+// element `part` of each coordinate.  park: slot s, limb l of this lane at park[(s * NL + l) * stride].
 template <class F30>
-G16_HD void window_table_task(const Fp<typename TableLane<F30>::B::Params>* src_pt, Fp<typename TableLane<F30>::B::Params>* table_pt, uint64_t row_stride,
-                              int c, int W, uint32_t* park, uint64_t stride) {
+struct TableDeviceIO {
     typedef TableLane<F30> TL;
     typedef typename TL::B B;
-    typedef Fp<typename B::Params> W32;   // one packed base-field element
-    constexpr int NL = B::NL;
-    const int k = TL::part();
-    const W32 xs = src_pt[k], ys = src_pt[TL::PARTS + k];
-    const bool ident = TL::all(xs.is_zero() && ys.is_zero());
-    if (ident) {
-        const W32 z = W32::zero();
-        for (int j = 0; j < W; ++j) { table_pt[(uint64_t)j * row_stride + k] = z; table_pt[(uint64_t)j * row_stride + TL::PARTS + k] = z; }
-        return;
+    typedef typename B::Std W32;           // one packed base-field element
+    static constexpr int NL = B::NL;
+    const W32* src_pt;
+    W32* table_pt;
+    uint64_t row_stride;                  // packed elements between two rows of the table
+    uint32_t* park;
+    uint64_t stride;
+    G16_HD bool load(F30& x, F30& y) const {
+        const int k = TL::part();
+        const W32 xs = src_pt[k], ys = src_pt[TL::PARTS + k];
+        if (TL::all(xs.is_zero() && ys.is_zero())) return false;
+        const W32 x0 = B::std_to_r30(xs), y0 = B::std_to_r30(ys);   // canonical x R', y R'
+        x = TL::wrap(B::unpack(x0.v));
+        y = TL::wrap(B::unpack(y0.v));
+        return true;
     }
-    const W32 x0 = B::std_to_r30(xs), y0 = B::std_to_r30(ys);   // canonical x R', y R'
-    table_pt[k] = x0;
-    table_pt[TL::PARTS + k] = y0;
-    F30 X = TL::wrap(B::unpack(x0.v)), Y = TL::wrap(B::unpack(y0.v)), Z = F30::one(), run = F30::one();
-    auto put = [&](int slot, const F30& v) {
+    G16_HD void store(int row, const F30& x, const F30& y) const {
+        const int k = TL::part();
+        W32 ox, oy;
+        TL::comp(x).pack(ox.v);
+        TL::comp(y).pack(oy.v);
+        table_pt[(uint64_t)row * row_stride + k] = ox;
+        table_pt[(uint64_t)row * row_stride + TL::PARTS + k] = oy;
+    }
+    G16_HD void store_identity(int row) const {
+        const int k = TL::part();
+        table_pt[(uint64_t)row * row_stride + k] = W32::zero();
+        table_pt[(uint64_t)row * row_stride + TL::PARTS + k] = W32::zero();
+    }
+    G16_HD void put(int slot, const F30& v) const {
         const B& b = TL::comp(v);
         G16_UNROLL for (int l = 0; l < NL; ++l) park[((uint64_t)slot * NL + l) * stride] = b.l[l];
-    };
-    auto get = [&](int slot) -> F30 {
+    }
+    G16_HD F30 get(int slot) const {
         B b;
         G16_UNROLL for (int l = 0; l < NL; ++l) b.l[l] = park[((uint64_t)slot * NL + l) * stride];
         return TL::wrap(b);
-    };
-    // forward: rows 1 .. live - 1 are finite; a point of 2-power order (never a subgroup point of these curves, but the caller's
-    // bases are not checked) reaches the identity at some row, from which on every row is the identity
-    int live = W;
-    for (int j = 1; j < W; ++j) {
-        for (int d = 0; d < c; ++d) jac30_double(X, Y, Z);
-        if (TL::all(TL::comp(Z).maybe_zero()) && TL::all(TL::comp(Z).is_zero_exact())) { live = j; break; }
-        put(4 * (j - 1) + 0, X);
-        put(4 * (j - 1) + 1, Y);
-        put(4 * (j - 1) + 2, Z);
-        put(4 * (j - 1) + 3, run);   // product of the Z's of rows 1 .. j - 1
-        run = run.mul(Z);
     }
-    F30 inv = batch_inverse(run);     // run != 0: a product of non-zero Z's (or one)
-    const W32 zero = W32::zero();
-    for (int j = W - 1; j >= live; --j) { table_pt[(uint64_t)j * row_stride + k] = zero; table_pt[(uint64_t)j * row_stride + TL::PARTS + k] = zero; }
-    for (int j = live - 1; j >= 1; --j) {
-        const F30 Zj = get(4 * (j - 1) + 2);
-        const F30 zi = inv.mul(get(4 * (j - 1) + 3));   // 1 / Z_j
-        inv = inv.mul(Zj);
-        const F30 zi2 = zi.sqr();
-        const F30 ax = get(4 * (j - 1) + 0).mul(zi2);              // X / Z^2
-        const F30 ay = get(4 * (j - 1) + 1).mul(zi2.mul(zi));      // Y / Z^3
-        W32 ox, oy;
-        TL::comp(ax).canonical_lt2p().pack(ox.v);
-        TL::comp(ay).canonical_lt2p().pack(oy.v);
-        table_pt[(uint64_t)j * row_stride + k] = ox;
-        table_pt[(uint64_t)j * row_stride + TL::PARTS + k] = oy;
-    }
-}
+    G16_HD bool is_zero(const F30& v) const { return TL::all(TL::comp(v).maybe_zero()) && TL::all(TL::comp(v).is_zero_exact()); }
+    G16_HD F30 canonical(const F30& v) const { return TL::wrap(TL::comp(v).canonical_lt2p()); }
+};
 
 }  // namespace g16

@@ -47,9 +47,13 @@ while [ $# -gt 0 ]; do
       find $O/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv; rm -rf $O/prof_stats
       head -12 $O/kernel_stats.csv ;;
     pmc)
+      # the known-bytes kernels and the bench under the SAME counter configuration, back to back on this box (two rocprofv3
+      # processes: one output directory each, their CSVs share a file name)
       for c in FETCH_SIZE WRITE_SIZE; do
-        timeout 600 rocprofv3 --pmc $c -d $O/pmc_$c -o pmc --output-format csv -- bash -c \
-          "tools/bin/calib > $O/calib_$c.jsonl && python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_pmc_$c.json 2> $O/bench_pmc_$c.err"
+        mkdir -p $O/pmc_$c
+        timeout 200 rocprofv3 --pmc $c -d $O/pmc_$c/calib -o pmc --output-format csv -- tools/bin/calib > $O/calib_$c.jsonl 2> $O/calib_$c.err
+        timeout 600 rocprofv3 --pmc $c -d $O/pmc_$c/bench -o pmc --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline \
+          > $O/bench_pmc_$c.json 2> $O/bench_pmc_$c.err
         echo "pmc $c rc=$?"
       done
       python tools/pmc_summary.py traffic $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/calib_FETCH_SIZE.jsonl > $O/pmc_traffic_calibrated.json
