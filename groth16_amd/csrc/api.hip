@@ -67,6 +67,8 @@ struct g16_ctx {
     hipStream_t stream;   // bucket passes, digit/sort
     hipStream_t stream2;  // witness digit/sort pass, then the latency-bound reductions underneath the bucket passes
     hipStream_t stream3;  // h's digit/sort pass, underneath the first bucket pass
+    hipStream_t stream_wm = nullptr;   // g16_dwm_stage_async: the distributed witness map's stages (and the caller's exchanges between them)
+    hipEvent_t ev_dwm = nullptr;
     hipStream_t red[5];   // one stream per MSM for its reductions: they are chains of dependent additions in a few waves
                           // (G2: ~9 ms), so five of them side by side end sooner than one after the other
     Arena arena;
@@ -91,6 +93,7 @@ struct DrainOnError {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipStreamSynchronize(ctx->stream_wm);
         for (int i = 0; i < 5; ++i) (void)hipStreamSynchronize(ctx->red[i]);
     }
 };
@@ -391,8 +394,13 @@ struct Impl {
         ScalarSort sort_h, sort_z, sort_l;
         G16_TRY(ctx->t_wm.start(s1));
         if (h_ext) {
+            // h comes from the distributed map: whatever g16_dwm_stage_async (and the caller's exchanges) enqueued on the
+            // witness-map stream must have finished before h is read -- by the h sort and the h MSM only; the witness sort and
+            // the four h-independent passes below start at once
             d_h = const_cast<Fr*>(h_ext);
             ctx->t_ntt[0].used = ctx->t_ntt[1].used = false;
+            G16_HIP_TRY(hipEventRecord(ctx->ev_dwm, ctx->stream_wm));
+            G16_HIP_TRY(hipStreamWaitEvent(s3, ctx->ev_dwm, 0));
         } else {
             G16_TRY(ctx->arena.alloc_n(n, &d_h));
             G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1, ctx->t_ntt)));
@@ -426,21 +434,20 @@ struct Impl {
         }
         char* pin = static_cast<char*>(ctx->pinned);
         if (sort_z.plan.outputs() > MSM_MAX_OUTPUTS || sort_h.plan.outputs() > MSM_MAX_OUTPUTS) return G16_ERR_INTERNAL;
-        // bucket pass on stream 1; reduction + copy-out underneath the following passes.  A reduction is a chain of
-        // dependent additions in a few waves (G1 ~1.5 ms, G2 ~9 ms, independent of the shard size).  Long passes (whole
-        // key): all reductions queue on stream 2 -- side by side they take more from the passes than they give back
-        // (measured 88.5 vs 82.0 ms at 2^22).  Short passes (a 1/4 .. 1/8 shard): one stream per MSM, otherwise the
-        // queue of reductions outlasts the passes (25.6 -> 23.0 ms per rank at 8 shards).
+        // Bucket passes back to back on stream 1.  The G2 MSM goes first and its reduction (the longest chain: ~3x a G1 one) runs on
+        // its own stream underneath the G1 passes; the four G1 reductions are NOT started one by one underneath the following
+        // pass -- a reduction is a few hundred waves of dependent additions that hold register slots for milliseconds and slowed
+        // every pass they ran under (8-way shard at 2^22: 1.8-2.1 ms per pass instead of 1.2) -- but run TOGETHER, one launch per
+        // stage for all of them (msm_reduce_batch), after the last pass: 4x the waves per launch, one chain of latency instead of four.
         const bool short_passes = (uint64_t)pk->a_count * (uint64_t)sort_z.plan.W < 20000000ull;
-        auto run_msm = [&](int k, auto* bases, int64_t shift, uint64_t count, const ScalarSort& ss, auto* buf) -> int {
-            typedef typename std::remove_pointer<decltype(buf)>::type Buf;
-            hipStream_t sr = short_passes ? ctx->red[k] : s2;
+        auto run_pass = [&](int k, auto* bases, int64_t shift, uint64_t count, const ScalarSort& ss, auto* buf) -> int {
             G16_HIP_TRY(hipEventRecord(ctx->ev_msm_start[k], s1));
             G16_TRY((msm_bucket_pass(bases, shift, count, ss, ctx->arena, s1, buf, &ctx->t_bucket[k])));
             G16_HIP_TRY(hipEventRecord(ctx->ev_acc[k], s1));
-            G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_acc[k], 0));
-            G16_TRY((msm_reduce(*buf, ss, sr)));
-            G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf->window_sums, sizeof(*Buf().window_sums) * ss.plan.outputs(), hipMemcpyDeviceToHost, sr));
+            return G16_OK;
+        };
+        auto copy_out = [&](int k, const auto& buf, const ScalarSort& ss, hipStream_t sr) -> int {
+            G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf.window_sums, sizeof(*buf.window_sums) * ss.plan.outputs(), hipMemcpyDeviceToHost, sr));
             G16_HIP_TRY(hipEventRecord(ctx->ev_done[k], sr));
             return G16_OK;
         };
@@ -448,21 +455,51 @@ struct Impl {
         // l_aux_acc = msm(l_query, aux) (prover.rs:70-74); aux[j] = assignment[j + nin - 1]
         const bool l_covered = pk->l_count == 0 || (pk->l_start + nin - 1 >= pk->a_start &&
                                                     pk->l_start + pk->l_count + nin - 1 <= pk->a_start + pk->a_count);
-        // the G2 MSM goes first: its reduction is the longest and hides under the G1 bucket passes
-        G16_TRY(run_msm(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2));                                   // prover.rs:113
+        {
+            hipStream_t sr = short_passes ? ctx->red[4] : s2;
+            G16_TRY(run_pass(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2));                               // prover.rs:113
+            G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_acc[4], 0));
+            G16_TRY((msm_reduce(buf_b2, sort_z, sr)));
+            G16_TRY(copy_out(4, buf_b2, sort_z, sr));
+        }
+        struct G1Job { int k; MsmBuffers<Fq>* buf; const ScalarSort* ss; };
+        G1Job jobs[4];
+        int njobs = 0;
         if (l_covered) {
             const int64_t shift = (int64_t)pk->a_start - (int64_t)(nin - 1) - (int64_t)pk->l_start;
-            G16_TRY(run_msm(1, pk->l, shift, pk->l_count, sort_z, &buf_l));
+            G16_TRY(run_pass(1, pk->l, shift, pk->l_count, sort_z, &buf_l));
+            jobs[njobs++] = {1, &buf_l, &sort_z};
         } else {
             G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, pk->c_z, ctx->arena, s1, &sort_l)));
-            G16_TRY(run_msm(1, pk->l, 0, pk->l_count, sort_l, &buf_l));
+            G16_TRY(run_pass(1, pk->l, 0, pk->l_count, sort_l, &buf_l));
+            jobs[njobs++] = {1, &buf_l, &sort_l};
         }
-        G16_TRY(run_msm(2, pk->a, 0, pk->a_count, sort_z, &buf_a));                                          // prover.rs:92
+        G16_TRY(run_pass(2, pk->a, 0, pk->a_count, sort_z, &buf_a));                                         // prover.rs:92
+        jobs[njobs++] = {2, &buf_a, &sort_z};
         ctx->t_bucket[3].used = false;
-        if (!skip_b_g1) G16_TRY(run_msm(3, pk->b_g1, 0, pk->b_g1_count, sort_z, &buf_b1));                  // prover.rs:98-108
+        if (!skip_b_g1) {                                                                                    // prover.rs:98-108
+            G16_TRY(run_pass(3, pk->b_g1, 0, pk->b_g1_count, sort_z, &buf_b1));
+            jobs[njobs++] = {3, &buf_b1, &sort_z};
+        }
         // ---- h_acc = msm(h_query, h) (prover.rs:63-66): needs the witness map
         G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_h, 0));
-        G16_TRY(run_msm(0, pk->h, 0, pk->h_count, sort_h, &buf_h));
+        G16_TRY(run_pass(0, pk->h, 0, pk->h_count, sort_h, &buf_h));
+        jobs[njobs++] = {0, &buf_h, &sort_h};
+        // the G1 reductions, batched by bucket layout (h's window size may differ from the witness MSMs')
+        bool done[4] = {false, false, false, false};
+        for (int i = 0; i < njobs; ++i) {
+            if (done[i]) continue;
+            const MsmBuffers<Fq>* bb[4];
+            const ScalarSort* sp[4];
+            int idx[4], nb = 0;
+            for (int q = i; q < njobs; ++q)
+                if (!done[q] && jobs[q].ss->plan.B == jobs[i].ss->plan.B && jobs[q].ss->plan.groups == jobs[i].ss->plan.groups) {
+                    bb[nb] = jobs[q].buf; sp[nb] = jobs[q].ss; idx[nb] = q; ++nb;
+                    done[q] = true;
+                }
+            G16_TRY((msm_reduce_batch<Fq>(bb, sp, nb, s1)));
+            for (int q = 0; q < nb; ++q) G16_TRY(copy_out(jobs[idx[q]].k, *jobs[idx[q]].buf, *jobs[idx[q]].ss, s1));
+        }
 
         // ---- host: fold sum_w 2^(cw) R_w per MSM as its window sums arrive (the GPU is still busy with later MSMs)
         double fold_ms = 0.0;
@@ -630,21 +667,27 @@ struct Impl {
         return G16_OK;
     }
 
+    // async: enqueue on the witness-map stream and return (the caller's exchange goes on that stream too: g16_ctx_wm_stream)
     static int dwm_stage_api(g16_ctx* ctx, const g16_circuit* ckh, const void* dwp, int stage, const uint64_t* z, uint64_t n_assign, int on_device,
-                             uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local) {
+                             uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local, bool async) {
         const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
         const DistWm<C>* dw = static_cast<const DistWm<C>*>(dwp);
         DrainOnError drain(ctx);
         const Fr* d_z = nullptr;
         if (stage == 0) {
             if (!z || n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
-            ctx->arena.reset();
-            G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
+            if (async) {
+                if (!on_device) return G16_ERR_BAD_ARG;   // a staged host copy would live in the arena the next call resets
+                d_z = reinterpret_cast<const Fr*>(z);
+            } else {
+                ctx->arena.reset();
+                G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
+            }
         }
         Fr* w[3] = {reinterpret_cast<Fr*>(work[0]), reinterpret_cast<Fr*>(work[1]), reinterpret_cast<Fr*>(work[2])};
         Fr* rv[3] = {reinterpret_cast<Fr*>(recv[0]), reinterpret_cast<Fr*>(recv[1]), reinterpret_cast<Fr*>(recv[2])};
-        G16_TRY((dwm_stage<C>(ck, dw, stage, d_z, w, rv, reinterpret_cast<Fr*>(h_local), ctx->stream)));
-        G16_HIP_TRY(hipStreamSynchronize(ctx->stream));   // the caller's exchange runs on its own stream
+        G16_TRY((dwm_stage<C>(ck, dw, stage, d_z, w, rv, reinterpret_cast<Fr*>(h_local), async ? ctx->stream_wm : ctx->stream)));
+        if (!async) G16_HIP_TRY(hipStreamSynchronize(ctx->stream));   // the caller's exchange runs on its own stream
         drain.dismiss();
         return G16_OK;
     }
@@ -992,6 +1035,8 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
     bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->stream_wm, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_dwm, hipEventDisableTiming) == hipSuccess &&
               hipStreamCreateWithPriority(&c->red[0], hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->red[1], hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->red[2], hipStreamNonBlocking, prio_hi) == hipSuccess &&
@@ -1062,6 +1107,7 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream3);
+    (void)hipStreamSynchronize(ctx->stream_wm);
     for (int i = 0; i < 5; ++i) (void)hipStreamSynchronize(ctx->red[i]);
     ctx->arena.release();
     ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy(); ctx->t_ntt[0].destroy(); ctx->t_ntt[1].destroy();
@@ -1069,7 +1115,8 @@ void g16_ctx_destroy(g16_ctx* ctx) {
         ctx->t_bucket[i].destroy();
         (void)hipEventDestroy(ctx->ev_acc[i]); (void)hipEventDestroy(ctx->ev_done[i]); (void)hipEventDestroy(ctx->ev_msm_start[i]);
     }
-    (void)hipEventDestroy(ctx->ev_z); (void)hipEventDestroy(ctx->ev_h); (void)hipEventDestroy(ctx->ev_wm);
+    (void)hipEventDestroy(ctx->ev_z); (void)hipEventDestroy(ctx->ev_h); (void)hipEventDestroy(ctx->ev_wm); (void)hipEventDestroy(ctx->ev_dwm);
+    (void)hipStreamDestroy(ctx->stream_wm);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
@@ -1079,6 +1126,7 @@ void g16_ctx_destroy(g16_ctx* ctx) {
 }
 
 void* g16_ctx_stream(g16_ctx* ctx) { return ctx ? (void*)(ctx->subs.empty() ? ctx->stream : ctx->subs[0]->stream) : nullptr; }
+void* g16_ctx_wm_stream(g16_ctx* ctx) { return ctx ? (void*)(ctx->subs.empty() ? ctx->stream_wm : ctx->subs[0]->stream_wm) : nullptr; }
 
 int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
     if (!ctx || !view || !out) return G16_ERR_BAD_ARG;
@@ -1255,16 +1303,21 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
         int rc;
         double dwm_ms = 0.0;
         if (pk->dist_n) {
-            // distributed witness map: every device's thread runs its four stages; after stages 0, 1 (a, b, c) and 2 (the quotient)
-            // device i PULLS chunk i of every device's work array into slot q of its recv array (peer copies over xGMI), the
-            // barriers stand for the collective's synchronisation; then the MSMs over this device's block of h
+            // distributed witness map: every device's thread ENQUEUES its four stages on its witness-map stream; after stages 0, 1
+            // (a, b, c) and 2 (the quotient) device i PULLS chunk i of every device's work array into slot q of its recv array
+            // (peer copies over xGMI).  Ordering is by events, not by waiting for the GPU: a pull waits on the sources' stage
+            // events, the next stage (which overwrites work[]) on the pullers' pull events; the host barriers only make sure an
+            // event has been recorded before somebody waits on it.  Then the MSMs: the witness sort and the four h-independent
+            // passes start at once, the h MSM follows the map (g16_prove_partial_h orders itself after the witness-map stream).
             if (n_assign != circuit->num_variables) return G16_ERR_BAD_LENGTH;
             HostBarrier bar(n);
             std::atomic<int> failed{0};
             const uint64_t M = circuit->domain_size / (uint64_t)n, blk = M / (uint64_t)n;
+            std::vector<hipEvent_t> ev_stage((size_t)n, nullptr), ev_pull((size_t)n, nullptr), ev_up((size_t)n, nullptr);
             rc = for_each_device(n, [&](int i) -> int {
                 g16_ctx* sub = ctx->subs[(size_t)i];
                 const DwmSlot& sl = circuit->dist[(size_t)i];
+                hipStream_t sw = sub->stream_wm;
                 int my = G16_OK;
                 int step_no = 0;
                 const bool dbg = getenv("G16_DEBUG") != nullptr;
@@ -1278,32 +1331,59 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                 const uint64_t* zp = full_assignment;
                 step([&]() -> int {
                     G16_HIP_TRY(hipSetDevice(sub->device));
+                    G16_HIP_TRY(hipEventCreateWithFlags(&ev_stage[(size_t)i], hipEventDisableTiming));
+                    G16_HIP_TRY(hipEventCreateWithFlags(&ev_pull[(size_t)i], hipEventDisableTiming));
+                    G16_HIP_TRY(hipEventCreateWithFlags(&ev_up[(size_t)i], hipEventDisableTiming));
                     if (!assignment_on_device) {
-                        G16_HIP_TRY(hipMemcpyAsync(sl.z_dev, full_assignment, n_assign * 32, hipMemcpyHostToDevice, sub->stream));
-                        G16_HIP_TRY(hipStreamSynchronize(sub->stream));
+                        G16_HIP_TRY(hipMemcpyAsync(sl.z_dev, full_assignment, n_assign * 32, hipMemcpyHostToDevice, sw));
                         zp = sl.z_dev;
                     }
+                    G16_HIP_TRY(hipEventRecord(ev_up[(size_t)i], sw));
                     return G16_OK;
                 });
                 const double tw = now_ms();
                 for (int st = 0; st < 4; ++st) {
-                    step([&]() -> int { return g16_dwm_stage(sub, sl.dwm, st, zp, n_assign, 1, sl.work, sl.recv, sl.h_local); });
-                    if (st == 3) break;
                     step([&]() -> int {
+                        G16_TRY(g16_dwm_stage_async(sub, sl.dwm, st, zp, n_assign, sl.work, sl.recv, sl.h_local));
+                        if (st < 3) G16_HIP_TRY(hipEventRecord(ev_stage[(size_t)i], sw));
+                        return G16_OK;
+                    });
+                    if (st == 3) break;
+                    step([&]() -> int {   // every device's stage event is recorded: pull
                         G16_HIP_TRY(hipSetDevice(sub->device));
+                        for (int q = 0; q < n; ++q) G16_HIP_TRY(hipStreamWaitEvent(sw, ev_stage[(size_t)q], 0));
                         for (int a = 0; a < (st < 2 ? 3 : 1); ++a)
                             for (int q = 0; q < n; ++q)
                                 G16_HIP_TRY(hipMemcpyPeerAsync(sl.recv[a] + (uint64_t)q * blk * 4, sub->device,
                                                                circuit->dist[(size_t)q].work[a] + (uint64_t)i * blk * 4, ctx->subs[(size_t)q]->device,
-                                                               blk * 32, sub->stream));
-                        G16_HIP_TRY(hipStreamSynchronize(sub->stream));
+                                                               blk * 32, sw));
+                        G16_HIP_TRY(hipEventRecord(ev_pull[(size_t)i], sw));
+                        return G16_OK;
+                    });
+                    step([&]() -> int {   // every pull is enqueued: my next stage may overwrite work[] only after all of them
+                        G16_HIP_TRY(hipSetDevice(sub->device));
+                        for (int q = 0; q < n; ++q) G16_HIP_TRY(hipStreamWaitEvent(sw, ev_pull[(size_t)q], 0));
                         return G16_OK;
                     });
                 }
-                if (i == 0) dwm_ms = now_ms() - tw;
-                if (failed.load() || my) return my ? my : SIBLING_FAILED;
-                return g16_prove_partial_h(sub, pk->subs[(size_t)i], circuit->subs[(size_t)i], zp, n_assign, 1, sl.h_local, M, skip_b_g1,
-                                           &parts[(size_t)i]);
+                if (i == 0) dwm_ms = now_ms() - tw;   // host time to enqueue the map (the GPU runs it underneath the first MSMs' sorts)
+                int out_rc = my;
+                if (!failed.load() && my == G16_OK) {
+                    // the uploaded assignment is read by the MSM streams too: order them after the upload
+                    if (hipStreamWaitEvent(sub->stream, ev_up[(size_t)i], 0) != hipSuccess) out_rc = G16_ERR_HIP;
+                    else
+                        out_rc = g16_prove_partial_h(sub, pk->subs[(size_t)i], circuit->subs[(size_t)i], zp, n_assign, 1, sl.h_local, M, skip_b_g1,
+                                                     &parts[(size_t)i]);
+                } else if (my == G16_OK) {
+                    out_rc = SIBLING_FAILED;
+                }
+                (void)hipSetDevice(sub->device);
+                (void)hipStreamSynchronize(sw);
+                bar.wait();   // nobody destroys an event another device's stream may still be waiting on
+                if (ev_stage[(size_t)i]) (void)hipEventDestroy(ev_stage[(size_t)i]);
+                if (ev_pull[(size_t)i]) (void)hipEventDestroy(ev_pull[(size_t)i]);
+                if (ev_up[(size_t)i]) (void)hipEventDestroy(ev_up[(size_t)i]);
+                return out_rc;
             });
         } else {
             rc = for_each_device(n, [&](int i) -> int {
@@ -1377,7 +1457,17 @@ int g16_dwm_stage(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assi
         (stage == 2 && (!work[0] || !recv[0] || !recv[1] || !recv[2])) || (stage == 3 && (!recv[0] || !h_local)))
         return G16_ERR_BAD_ARG;
     G16_HIP_TRY(hipSetDevice(ctx->device));
-    G16_DISPATCH(ctx->curve, I::dwm_stage_api(ctx, d->circuit, d->dw, stage, full_assignment, n_assign, assignment_on_device, work, recv, h_local));
+    G16_DISPATCH(ctx->curve, I::dwm_stage_api(ctx, d->circuit, d->dw, stage, full_assignment, n_assign, assignment_on_device, work, recv, h_local, false));
+}
+
+int g16_dwm_stage_async(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assignment_dev, uint64_t n_assign, uint64_t* const work[3],
+                        uint64_t* const recv[3], uint64_t* h_local) {
+    if (!ctx || !d || d->ctx != ctx || !work || !recv || stage < 0 || stage > 3) return G16_ERR_BAD_ARG;
+    if ((stage == 0 && (!work[0] || !work[1] || !work[2])) || (stage == 1 && (!work[0] || !work[1] || !work[2] || !recv[0] || !recv[1] || !recv[2])) ||
+        (stage == 2 && (!work[0] || !recv[0] || !recv[1] || !recv[2])) || (stage == 3 && (!recv[0] || !h_local)))
+        return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::dwm_stage_api(ctx, d->circuit, d->dw, stage, full_assignment_dev, n_assign, 1, work, recv, h_local, true));
 }
 
 int g16_get_timings(g16_ctx* ctx, g16_timings* out) {

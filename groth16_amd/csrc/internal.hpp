@@ -218,6 +218,9 @@ struct MsmBuffers {
 template <class F> int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena,
                                        hipStream_t st, MsmBuffers<F>* out, EventTimer* bucket_timer);
 template <class F> int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st);
+// the reductions of n <= 4 MSMs whose plans have the same bucket layout as ONE launch per stage (they fill the chip together
+// instead of each occupying a corner of it underneath the next MSM's bucket pass); G16_ERR_INTERNAL if the plans differ
+template <class F> int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st);
 // MSM bases are kept on the device in the bucket kernel's own Montgomery radix (x*R' with R' = 2^(30 NL), canonical,
 // packed in the usual words): converted in place, once, after upload (F = Fq for G1, Fq2 for G2).
 template <class F> int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st);

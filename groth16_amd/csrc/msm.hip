@@ -475,13 +475,30 @@ template <class P> struct Lazy30<Fp2<P>> {
 static constexpr int HEAVY_THREADS = 128;
 static constexpr int HEAVY_BLOCKS = 512;
 
+// The reductions of up to REDUCE_BATCH MSMs run as ONE launch each (blockIdx.y / .z = MSM of the batch): a reduction is a chain of
+// dependent additions in a few hundred waves, so one MSM's reduction alone leaves most of the chip idle, and run underneath the next
+// MSM's bucket pass it takes register slots from it for milliseconds (8-way shard at 2^22: 1.8-2.1 ms per pass instead of 1.2).
+// The prover therefore runs its four G1 bucket passes back to back and reduces them together.  All MSMs of a batch share the plan
+// (bucket count, chunking); slot offsets / heavy lists are per MSM (h has its own sort).
+static constexpr int REDUCE_BATCH = 4;
+template <class Raw, class X>
+struct ReduceBatch {
+    Raw* partials[REDUCE_BATCH];
+    const uint32_t* slot_off[REDUCE_BATCH];
+    const uint32_t* heavy[REDUCE_BATCH];
+    Raw* chunk_out[REDUCE_BATCH];       // weighted chunk sums, then (at + chunks) the plain chunk sums
+    X* window_sums[REDUCE_BATCH];
+};
+
 // (task = one lane, or one lane pair for the lane-pair Fq2: both lanes of a pair run the same control flow)
 template <class F30>
-__global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(AccRaw<typename F30::Raw>* __restrict__ partials, const uint32_t* __restrict__ slot_off,
-                                                                     const uint32_t* __restrict__ heavy) {
+__global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
     constexpr uint32_t LPT = F30::LANES_PER_TASK, TASKS = HEAVY_THREADS / LPT;
+    AccRaw<typename F30::Raw>* __restrict__ partials = batch.partials[blockIdx.y];
+    const uint32_t* __restrict__ slot_off = batch.slot_off[blockIdx.y];
+    const uint32_t* __restrict__ heavy = batch.heavy[blockIdx.y];
     const uint32_t nheavy = heavy[0], task = threadIdx.x / LPT;
     for (uint32_t i = blockIdx.x; i < nheavy; i += gridDim.x) {
         const uint32_t b = heavy[1 + i];
@@ -507,10 +524,13 @@ __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(AccRaw<type
 // 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
 // ---------------------------------------------------------------------------------------------
 template <class F30>
-__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw<typename F30::Raw>* __restrict__ partials,
-                                                                    const uint32_t* __restrict__ slot_off, uint32_t B, int W, uint32_t G,
-                                                                    AccRaw<typename F30::Raw>* __restrict__ chunk_out, AccRaw<typename F30::Raw>* __restrict__ chunk_sum) {
+__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t B, int W,
+                                                                    uint32_t G) {
+    const AccRaw<typename F30::Raw>* __restrict__ partials = batch.partials[blockIdx.y];
+    const uint32_t* __restrict__ slot_off = batch.slot_off[blockIdx.y];
     const uint32_t cpw = B / G;
+    AccRaw<typename F30::Raw>* __restrict__ chunk_out = batch.chunk_out[blockIdx.y];
+    AccRaw<typename F30::Raw>* __restrict__ chunk_sum = chunk_out + (size_t)cpw * W;
     const uint32_t t = (blockIdx.x * RED_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
     if (t >= cpw * (uint32_t)W) return;
     const uint32_t w = t / cpw, ch = t % cpw, b_lo = ch * G;
@@ -532,13 +552,14 @@ __global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(const AccRaw
 // grid = (groups, planes): plane 0 sums the chunks' weighted sums, plane 1 their plain sums, plane 2 + k the plain sums of the
 // chunks whose index has bit k set
 template <class F30>
-__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(const AccRaw<typename F30::Raw>* __restrict__ chunk_out,
-                                                                    const AccRaw<typename F30::Raw>* __restrict__ chunk_sum, uint32_t cpw,
-                                                                    XYZZ<typename F30::Std>* __restrict__ window_sums) {
+__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t cpw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
     constexpr uint32_t LPT = F30::LANES_PER_TASK, TASKS = WIN_THREADS / LPT;
     const uint32_t w = blockIdx.x, p = blockIdx.y, task = threadIdx.x / LPT;
+    const AccRaw<typename F30::Raw>* __restrict__ chunk_out = batch.chunk_out[blockIdx.z];
+    const AccRaw<typename F30::Raw>* __restrict__ chunk_sum = chunk_out + (size_t)cpw * gridDim.x;
+    XYZZ<typename F30::Std>* __restrict__ window_sums = batch.window_sums[blockIdx.z];
     const AccRaw<typename F30::Raw>* src = (p == 0 ? chunk_out : chunk_sum) + (uint64_t)w * cpw;
     const uint32_t mask = p >= 2 ? 1u << (p - 2) : 0u;
     Acc30<F30> acc = Acc30<F30>::identity();
@@ -903,10 +924,13 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
 }
 
 template <class F>
-int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
+int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st) {
     typedef typename Lazy30<F>::type F30;
     typedef AccRaw<typename F30::Raw> Raw;
-    const MsmPlan& plan = ss.plan;
+    if (n < 1 || n > REDUCE_BATCH) return G16_ERR_INTERNAL;
+    const MsmPlan& plan = sorts[0]->plan;
+    for (int i = 1; i < n; ++i)
+        if (sorts[i]->plan.B != plan.B || sorts[i]->plan.groups != plan.groups) return G16_ERR_INTERNAL;   // one launch = one plan
     const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
     const uint32_t cpw = plan.B / G;
     static PerDeviceOnce attr_once;
@@ -919,18 +943,30 @@ int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
                                         (int)lds_win));
         attr_set = true;
     }
-    Raw* partials = static_cast<Raw*>(buf.partials);
-    Raw* chunk_out = static_cast<Raw*>(buf.chunk_out);
-    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS), dim3(HEAVY_THREADS), lds_heavy, st, partials, ss.task_off, ss.heavy);
+    ReduceBatch<Raw, XYZZ<F>> batch;
+    for (int i = 0; i < REDUCE_BATCH; ++i) {
+        const int k = i < n ? i : 0;
+        batch.partials[i] = static_cast<Raw*>(bufs[k]->partials);
+        batch.slot_off[i] = sorts[k]->task_off;
+        batch.heavy[i] = sorts[k]->heavy;
+        batch.chunk_out[i] = static_cast<Raw*>(bufs[k]->chunk_out);
+        batch.window_sums[i] = bufs[k]->window_sums;
+    }
+    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, n), dim3(HEAVY_THREADS), lds_heavy, st, batch);
     G16_LAUNCH_CHECK();
-    Raw* chunk_sum = chunk_out + (size_t)cpw * plan.groups;
-    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, st,
-                       partials, ss.task_off, plan.B, plan.groups, G, chunk_out, chunk_sum);
+    hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, n), dim3(RED_THREADS), 0,
+                       st, batch, plan.B, plan.groups, G);
     G16_LAUNCH_CHECK();
-    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.groups, plan.planes()), dim3(WIN_THREADS), lds_win, st, chunk_out, chunk_sum, cpw,
-                       buf.window_sums);
+    hipLaunchKernelGGL((window_reduce_kernel<F30>), dim3(plan.groups, plan.planes(), n), dim3(WIN_THREADS), lds_win, st, batch, cpw);
     G16_LAUNCH_CHECK();
     return G16_OK;
+}
+
+template <class F>
+int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
+    const MsmBuffers<F>* b = &buf;
+    const ScalarSort* s = &ss;
+    return msm_reduce_batch<F>(&b, &s, 1, st);
 }
 
 template <class F>
@@ -1027,6 +1063,7 @@ int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine
     template int msm_bucket_pass<typename C::Fq2>(const Affine<typename C::Fq2>*, int64_t, uint64_t, const ScalarSort&,     \
                                                   Arena&, hipStream_t, MsmBuffers<typename C::Fq2>*, EventTimer*);            \
     template int msm_reduce<typename C::Fq>(const MsmBuffers<typename C::Fq>&, const ScalarSort&, hipStream_t);             \
+    template int msm_reduce_batch<typename C::Fq>(const MsmBuffers<typename C::Fq>* const*, const ScalarSort* const*, int, hipStream_t); \
     template int msm_reduce<typename C::Fq2>(const MsmBuffers<typename C::Fq2>&, const ScalarSort&, hipStream_t);           \
     template XYZZ<typename C::Fq> fold_windows<typename C::Fq>(const XYZZ<typename C::Fq>*, const MsmPlan&);               \
     template XYZZ<typename C::Fq2> fold_windows<typename C::Fq2>(const XYZZ<typename C::Fq2>*, const MsmPlan&);

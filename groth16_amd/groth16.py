@@ -596,16 +596,40 @@ class DistributedWitnessMap:
         """arrays exchanged after stage s (a, b, c after stages 0 and 1; the quotient after stage 2)"""
         return 3 if s < 2 else 1
 
+    def stage_async(self, s: int, z_dev_ptr: int = 0, n_assign: int = 0):
+        """g16_dwm_stage_async: the stage is enqueued on the context's witness-map stream and the call returns"""
+        self.lib.check(self.lib.c.g16_dwm_stage_async(self.ctx, self.handle, s, C.c_void_p(z_dev_ptr) if z_dev_ptr else None, n_assign,
+                                                      self._wp, self._rp, C.c_void_p(self.h_local.data_ptr())))
+
     def run(self, z_ptr: int, n_assign: int, on_device: bool, dist):
-        """all four stages with the exchanges over `dist` (torch.distributed); returns h_local"""
+        """all four stages with the exchanges over `dist` (torch.distributed); returns h_local.
+
+        Device-resident assignment + RCCL (or a single rank): NOTHING here waits on the host -- stages (g16_dwm_stage_async) and
+        exchanges (all_to_all_single: chunk p of work -> rank p, the chunk from rank q -> position q of recv) are enqueued on the
+        library's witness-map stream, which torch adopts as an external stream; the three arrays of an exchange step go
+        back to back.  A following prove_partial_h orders only its h sort / h MSM after this stream.  Otherwise (host assignment, or
+        gloo in the one-GPU / CPU tests, which has no all-to-all): stage by stage with host synchronisation."""
         import torch
 
+        multi = dist is not None and self.world > 1
+        if on_device and (not multi or dist.get_backend() == "nccl"):
+            ext = torch.cuda.ExternalStream(int(self.lib.c.g16_ctx_wm_stream(self.ctx)), device=self.h_local.device)
+            with torch.cuda.stream(ext):
+                for s in range(4):
+                    self.stage_async(s, z_ptr if s == 0 else 0, n_assign if s == 0 else 0)
+                    if s < 3:
+                        for m in range(self.arrays_after(s)):
+                            if multi:
+                                dist.all_to_all_single(self.recv[m], self.work[m])
+                            else:
+                                self.recv[m].copy_(self.work[m])
+            return self.h_local
         for s in range(4):
             self.stage(s, z_ptr if s == 0 else 0, n_assign if s == 0 else 0, on_device)
             if s < 3:
                 for m in range(self.arrays_after(s)):
                     src, dst = self.work[m], self.recv[m]
-                    if dist is not None and self.world > 1:
+                    if multi:
                         if dist.get_backend() == "nccl":
                             dist.all_to_all_single(dst, src)      # chunk p of src -> rank p; chunk from rank q -> position q
                         else:   # gloo (one-GPU / CPU tests) has no all-to-all: gather everything on the host, keep my chunks

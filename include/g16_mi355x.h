@@ -181,6 +181,13 @@ void g16_dwm_free(g16_dwm* d);
 uint64_t g16_dwm_local_size(const g16_dwm* d);
 int g16_dwm_stage(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assignment, uint64_t n_assign, int assignment_on_device,
                   uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local);
+/* The same stages WITHOUT host synchronisation: the stage is enqueued on the context's witness-map stream (g16_ctx_wm_stream) and the
+ * call returns; the caller enqueues its exchange on that SAME stream (e.g. torch.cuda.ExternalStream), so stages and exchanges are
+ * ordered by the stream alone.  full_assignment must be device memory.  A following g16_prove_partial_h orders its h sort / h MSM
+ * after everything enqueued on that stream; its witness sort and the four h-independent MSMs (prover.rs:74,92,105,113) do not wait. */
+void* g16_ctx_wm_stream(g16_ctx* ctx);
+int g16_dwm_stage_async(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assignment_dev, uint64_t n_assign,
+                        uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local);
 /* g16_prove_partial with h supplied by the caller (device memory, h_len Fr; the key's h shard indexes it from h.start) */
 int g16_prove_partial_h(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
                         int assignment_on_device, const uint64_t* h_dev, uint64_t h_len, int skip_b_g1, g16_partial* out);

@@ -114,3 +114,31 @@ def test_sharded_proof_with_distributed_h(g, orc, curve, k, world):
             assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
         for d in ranks:
             d.close()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("k", [6, 13])
+def test_async_stages_one_rank_then_proof(g, orc, curve, k):
+    """g16_dwm_stage_async: the four stages (world = 1: the exchanges are device copies) enqueued on the library's witness-map
+    stream through torch's ExternalStream with NO host synchronisation, g16_prove_partial_h right behind them -- its h MSM must
+    order itself after that stream, its witness sort must not need it.  Proof == oracle's, then h == oracle's."""
+    import torch
+    from groth16_amd.groth16 import DistributedWitnessMap
+
+    ck = orc.syn_circuit(curve, k, 23 + k)
+    pk, _ = orc.setup(ck, 3)
+    gm, gp = mats_of(g, ck), pk_of(g, pk)
+    r, s = orc.rand_fr(curve, 71, 1)[0], orc.rand_fr(curve, 72, 1)[0]
+    with g.Groth16(curve, 0) as prover:
+        dck = prover._ck(gm)
+        d = DistributedWitnessMap(prover._ctx.lib, prover._ctx.handle, dck.handle, 0, 1, "cuda:0")
+        z_dev = torch.from_numpy(np.ascontiguousarray(ck.z).view(np.int64)).to("cuda:0")
+        torch.cuda.synchronize()
+        for _ in range(3):   # repeated: stale events / buffers of an earlier round must not satisfy a later one
+            h = d.run(z_dev.data_ptr(), z_dev.shape[0], True, None)
+            part = prover.prove_partial_h(gp, gm, ck.z, (0, 1), h.data_ptr(), d.M)
+            proof = prover.prove_finalize(gp, ck.num_inputs, [part], r, s, (0, 1), dist_h=True)
+            assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+        torch.cuda.synchronize()
+        assert (h.cpu().numpy().view(np.uint64) == orc.witness_map(ck)).all()
+        d.close()

@@ -5,6 +5,7 @@
 # Steps (each bounded by its own `timeout`, none combines --pmc with a trace domain):
 #   tests [pytest args]   python -m pytest tests -m gpu -q <args>            -> pytest.log
 #   newtests              the round-3 full-size parity cases only                   -> pytest_new.log
+#   fasttests             the GPU tier without the minute-long full-size cases      -> pytest_fast.log
 #   bench [bench args]    python bench.py <args>                               -> bench.json / bench.err
 #   stats                 rocprofv3 --kernel-trace --stats of bench.py --steps 5     -> kernel_stats.csv
 #   pmc                   tools/bin/calib + bench.py --steps 2 inside ONE rocprofv3 --pmc FETCH_SIZE pass and ONE --pmc WRITE_SIZE
@@ -31,6 +32,9 @@ while [ $# -gt 0 ]; do
     tests)
       args=""; while [ $# -gt 0 ] && [[ "$1" == -* || "$1" == tests/* ]]; do args="$args $1"; shift; done
       timeout 1500 python -m pytest tests -m gpu -q -x $args > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -5 $O/pytest.log ;;
+    fasttests)   # everything but the minute-long full-size cases (those run in `tests` / `newtests`)
+      timeout 1200 python -m pytest tests -m gpu -q -x --durations=10 -k "not k22 and not configs4 and not 2_24 and not 22-8 and not 20-8" > $O/pytest_fast.log 2>&1
+      echo "fasttests rc=$?" | tee -a $O/pytest_fast.log; tail -16 $O/pytest_fast.log ;;
     newtests)
       timeout 1200 python -m pytest -m gpu -q -x --durations=8 \
         "tests/test_gpu_fullsize.py::test_configs4_2_24_eight_ranks_distributed_map_block_h" \
