@@ -69,6 +69,7 @@ struct g16_ctx {
     hipStream_t stream3;  // h's digit/sort pass, underneath the first bucket pass
     hipStream_t stream_wm = nullptr;   // g16_dwm_stage_async: the distributed witness map's stages (and the caller's exchanges between them)
     hipEvent_t ev_dwm = nullptr;
+    hipEvent_t ev_heavy[4] = {};   // G1 MSM k's heavy-bucket combine (side stream) done
     hipStream_t red[5];   // one stream per MSM for its reductions: they are chains of dependent additions in a few waves
                           // (G2: ~9 ms), so five of them side by side end sooner than one after the other
     Arena arena;
@@ -180,8 +181,23 @@ struct Impl {
     // ---------------------------------------------------------------------------------------
     // one query array of the key on the device, ready for the bucket kernel: with c == 0 the bases themselves (converted
     // to the kernel's radix), else the W-row window table built from them; the caller's buffer is never modified
+    // load-time scratch shared by the five queries of one key: the window-table builders' parking buffer and the staged copies of
+    // host-side bases.  Nothing in load_query waits for the GPU; pk_load synchronises once and releases these.
+    struct LoadScratch {
+        void* park = nullptr;
+        size_t park_bytes = 0;
+        std::vector<void*> staged;
+        void release() {
+            (void)hipFree(park);
+            park = nullptr;
+            park_bytes = 0;
+            for (void* p : staged) (void)hipFree(p);
+            staged.clear();
+        }
+    };
+
     template <class F>
-    static int load_query(g16_ctx* ctx, const g16_query& q, bool dev_ptrs, int c, Affine<F>** out) {
+    static int load_query(g16_ctx* ctx, const g16_query& q, bool dev_ptrs, int c, Affine<F>** out, LoadScratch& ls) {
         typedef Affine<F> P;
         *out = nullptr;
         if (q.count == 0) return G16_OK;
@@ -201,21 +217,26 @@ struct Impl {
         if (cap && (double)q.count * sizeof(P) * W > atof(cap) * 1048576.0) return G16_ERR_OOM;
         if (hipMalloc((void**)out, q.count * sizeof(P) * (size_t)W) != hipSuccess) return G16_ERR_OOM;
         const P* src = reinterpret_cast<const P*>(q.points);
-        P* staged = nullptr;
         if (!dev_ptrs) {
+            P* staged = nullptr;
             if (hipMalloc((void**)&staged, q.count * sizeof(P)) != hipSuccess) return G16_ERR_OOM;
-            if (hipMemcpyAsync(staged, q.points, q.count * sizeof(P), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-                (void)hipFree(staged);
-                return G16_ERR_HIP;
-            }
+            ls.staged.push_back(staged);
+            G16_HIP_TRY(hipMemcpyAsync(staged, q.points, q.count * sizeof(P), hipMemcpyHostToDevice, ctx->stream));
             src = staged;
         }
-        int rc = build_window_tables<F>(src, q.count, c, W, *out, ctx->stream);
-        if (staged) {
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = rc ? rc : G16_ERR_HIP;
-            (void)hipFree(staged);
+        // the parking buffer is used by one build at a time (they are queued on one stream); it only ever grows
+        const size_t need = window_table_park_bytes<F>(q.count, W);
+        if (need > ls.park_bytes) {
+            if (ls.park) {   // an earlier build may still be using the smaller one
+                G16_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                (void)hipFree(ls.park);
+                ls.park = nullptr;
+                ls.park_bytes = 0;
+            }
+            if (hipMalloc(&ls.park, need) != hipSuccess) return G16_ERR_OOM;
+            ls.park_bytes = need;
         }
-        return rc;
+        return build_window_tables<F>(src, q.count, c, W, *out, ctx->stream, ls.park);
     }
 
     static void pk_free(DevicePk<C>* p) {
@@ -257,12 +278,15 @@ struct Impl {
         if (v->h.count == 0) p->c_h = p->c_z;
         if (nz == 0) p->c_z = p->c_h;
         if (p->c_z == 0 || p->c_h == 0) p->c_z = p->c_h = 0;   // tables for all queries or for none
+        LoadScratch ls;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const int cz = p->c_z, ch = p->c_h;
-            if ((rc = load_query<Fq>(ctx, v->a, dev, cz, &p->a)) || (rc = load_query<Fq>(ctx, v->b_g1, dev, cz, &p->b_g1)) ||
-                (rc = load_query<Fq2>(ctx, v->b_g2, dev, cz, &p->b_g2)) || (rc = load_query<Fq>(ctx, v->l, dev, cz, &p->l)) ||
-                (rc = load_query<Fq>(ctx, v->h, dev, ch, &p->h))) {
+            // the G2 table first: it needs the largest parking buffer
+            if ((rc = load_query<Fq2>(ctx, v->b_g2, dev, cz, &p->b_g2, ls)) || (rc = load_query<Fq>(ctx, v->a, dev, cz, &p->a, ls)) ||
+                (rc = load_query<Fq>(ctx, v->b_g1, dev, cz, &p->b_g1, ls)) || (rc = load_query<Fq>(ctx, v->l, dev, cz, &p->l, ls)) ||
+                (rc = load_query<Fq>(ctx, v->h, dev, ch, &p->h, ls))) {
                 (void)hipStreamSynchronize(ctx->stream);
+                ls.release();
                 (void)hipFree(p->a); (void)hipFree(p->b_g1); (void)hipFree(p->b_g2); (void)hipFree(p->h); (void)hipFree(p->l);
                 p->a = p->b_g1 = p->h = p->l = nullptr;
                 p->b_g2 = nullptr;
@@ -281,7 +305,9 @@ struct Impl {
         p->b_g2_start = v->b_g2.start; p->b_g2_count = v->b_g2.count;
         p->h_start = v->h.start; p->h_count = v->h.count;
         p->l_start = v->l.start; p->l_count = v->l.count;
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { pk_free(p); return G16_ERR_HIP; }
+        const bool load_ok = hipStreamSynchronize(ctx->stream) == hipSuccess;   // every table is built: the load-time scratch can go
+        ls.release();
+        if (!load_ok) { pk_free(p); return G16_ERR_HIP; }
         g16_pk* h = new (std::nothrow) g16_pk{C::CURVE_ID, ctx, p};
         if (!h) { pk_free(p); return G16_ERR_OOM; }
         *out = h;
@@ -446,6 +472,14 @@ struct Impl {
             G16_HIP_TRY(hipEventRecord(ctx->ev_acc[k], s1));
             return G16_OK;
         };
+        // a G1 MSM's heavy-bucket combine (buckets with many partial sums: the short top window's few hundred) goes underneath the
+        // next pass on the MSM's own stream -- at most a few hundred workgroups -- so that the batched reduction starts at the bucket level
+        auto heavy_early = [&](int k, const MsmBuffers<Fq>& buf, const ScalarSort& ss) -> int {
+            G16_HIP_TRY(hipStreamWaitEvent(ctx->red[k], ctx->ev_acc[k], 0));
+            G16_TRY((msm_heavy_reduce<Fq>(buf, ss, ctx->red[k])));
+            G16_HIP_TRY(hipEventRecord(ctx->ev_heavy[k], ctx->red[k]));
+            return G16_OK;
+        };
         auto copy_out = [&](int k, const auto& buf, const ScalarSort& ss, hipStream_t sr) -> int {
             G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf.window_sums, sizeof(*buf.window_sums) * ss.plan.outputs(), hipMemcpyDeviceToHost, sr));
             G16_HIP_TRY(hipEventRecord(ctx->ev_done[k], sr));
@@ -468,22 +502,27 @@ struct Impl {
         if (l_covered) {
             const int64_t shift = (int64_t)pk->a_start - (int64_t)(nin - 1) - (int64_t)pk->l_start;
             G16_TRY(run_pass(1, pk->l, shift, pk->l_count, sort_z, &buf_l));
+            G16_TRY(heavy_early(1, buf_l, sort_z));
             jobs[njobs++] = {1, &buf_l, &sort_z};
         } else {
             G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, pk->c_z, ctx->arena, s1, &sort_l)));
             G16_TRY(run_pass(1, pk->l, 0, pk->l_count, sort_l, &buf_l));
+            G16_TRY(heavy_early(1, buf_l, sort_l));
             jobs[njobs++] = {1, &buf_l, &sort_l};
         }
         G16_TRY(run_pass(2, pk->a, 0, pk->a_count, sort_z, &buf_a));                                         // prover.rs:92
+        G16_TRY(heavy_early(2, buf_a, sort_z));
         jobs[njobs++] = {2, &buf_a, &sort_z};
         ctx->t_bucket[3].used = false;
         if (!skip_b_g1) {                                                                                    // prover.rs:98-108
             G16_TRY(run_pass(3, pk->b_g1, 0, pk->b_g1_count, sort_z, &buf_b1));
+            G16_TRY(heavy_early(3, buf_b1, sort_z));
             jobs[njobs++] = {3, &buf_b1, &sort_z};
         }
         // ---- h_acc = msm(h_query, h) (prover.rs:63-66): needs the witness map
         G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_h, 0));
         G16_TRY(run_pass(0, pk->h, 0, pk->h_count, sort_h, &buf_h));
+        G16_TRY(heavy_early(0, buf_h, sort_h));
         jobs[njobs++] = {0, &buf_h, &sort_h};
         // the G1 reductions, batched by bucket layout (h's window size may differ from the witness MSMs')
         bool done[4] = {false, false, false, false};
@@ -497,30 +536,40 @@ struct Impl {
                     bb[nb] = jobs[q].buf; sp[nb] = jobs[q].ss; idx[nb] = q; ++nb;
                     done[q] = true;
                 }
-            G16_TRY((msm_reduce_batch<Fq>(bb, sp, nb, s1)));
+            for (int q = 0; q < nb; ++q) G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_heavy[jobs[idx[q]].k], 0));
+            G16_TRY((msm_reduce_batch<Fq>(bb, sp, nb, s1, /*heavy_done=*/true)));
             for (int q = 0; q < nb; ++q) G16_TRY(copy_out(jobs[idx[q]].k, *jobs[idx[q]].buf, *jobs[idx[q]].ss, s1));
         }
 
-        // ---- host: fold sum_w 2^(cw) R_w per MSM as its window sums arrive (the GPU is still busy with later MSMs)
+        // ---- host: fold the group sums of each MSM (merged plan: ~30 group operations per class, 0.25 ms per G1 MSM at c = 20,
+        // 0.7 ms for G2).  G2's sums arrive early and are folded while the GPU runs the G1 passes; the four G1 MSMs' sums arrive
+        // together at the very end, so their folds run side by side on host threads instead of one after the other.
         double fold_ms = 0.0;
-        auto fold_g1 = [&](int k, const MsmPlan& plan, uint64_t* dst) -> int {
-            G16_HIP_TRY(hipEventSynchronize(ctx->ev_done[k]));
-            const double t0 = now_ms();
-            store_xyzz(dst, fold_windows<Fq>(reinterpret_cast<const G1X*>(pin + k * SLOT), plan));
-            fold_ms += now_ms() - t0;
-            return G16_OK;
-        };
         {
             G16_HIP_TRY(hipEventSynchronize(ctx->ev_done[4]));
             const double t0 = now_ms();
             store_xyzz(out->b_g2, fold_windows<Fq2>(reinterpret_cast<const G2X*>(pin + 4 * SLOT), sort_z.plan));
             fold_ms += now_ms() - t0;
         }
-        G16_TRY(fold_g1(1, l_covered ? sort_z.plan : sort_l.plan, out->l));
-        G16_TRY(fold_g1(2, sort_z.plan, out->a));
-        if (!skip_b_g1) G16_TRY(fold_g1(3, sort_z.plan, out->b_g1));
-        else store_xyzz(out->b_g1, G1X::identity());
-        G16_TRY(fold_g1(0, sort_h.plan, out->h));
+        if (skip_b_g1) store_xyzz(out->b_g1, G1X::identity());
+        {
+            G16_HIP_TRY(hipEventSynchronize(ctx->ev_done[0]));   // recorded last on stream 1: every G1 copy-out has landed
+            const double t0 = now_ms();
+            struct FoldJob { int k; const MsmPlan* plan; uint64_t* dst; };
+            const FoldJob fj[4] = {{1, l_covered ? &sort_z.plan : &sort_l.plan, out->l}, {2, &sort_z.plan, out->a}, {3, &sort_z.plan, out->b_g1},
+                                   {0, &sort_h.plan, out->h}};
+            auto fold_one = [&](const FoldJob& f) { store_xyzz(f.dst, fold_windows<Fq>(reinterpret_cast<const G1X*>(pin + f.k * SLOT), *f.plan)); };
+            std::future<void> fut[3];
+            int nf = 0;
+            for (int q = 0; q < 3; ++q) {
+                if (fj[q].k == 3 && skip_b_g1) continue;
+                const FoldJob f = fj[q];
+                fut[nf++] = std::async(std::launch::async, [&fold_one, f]() { fold_one(f); });
+            }
+            fold_one(fj[3]);
+            for (int q = 0; q < nf; ++q) fut[q].get();
+            fold_ms += now_ms() - t0;
+        }
         G16_HIP_TRY(hipStreamSynchronize(s1));
         G16_HIP_TRY(hipStreamSynchronize(s2));
         G16_HIP_TRY(hipStreamSynchronize(s3));
@@ -1037,6 +1086,10 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
               hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream_wm, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_dwm, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_heavy[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_heavy[1], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_heavy[2], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_heavy[3], hipEventDisableTiming) == hipSuccess &&
               hipStreamCreateWithPriority(&c->red[0], hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->red[1], hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->red[2], hipStreamNonBlocking, prio_hi) == hipSuccess &&
@@ -1116,6 +1169,7 @@ void g16_ctx_destroy(g16_ctx* ctx) {
         (void)hipEventDestroy(ctx->ev_acc[i]); (void)hipEventDestroy(ctx->ev_done[i]); (void)hipEventDestroy(ctx->ev_msm_start[i]);
     }
     (void)hipEventDestroy(ctx->ev_z); (void)hipEventDestroy(ctx->ev_h); (void)hipEventDestroy(ctx->ev_wm); (void)hipEventDestroy(ctx->ev_dwm);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_heavy[i]);
     (void)hipStreamDestroy(ctx->stream_wm);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipStreamDestroy(ctx->stream);

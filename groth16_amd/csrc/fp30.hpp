@@ -329,6 +329,27 @@ struct Fp30 {
 
     // value < 8p (normalised) -> canonical [0, p): three conditional subtractions (~5 % of a product)
     G16_HD Fp30 canonical_lt8p() const { return cond_sub<4>().template cond_sub<2>().canonical_lt2p(); }
+    // ANY lazy value (normalised limbs, value < 2^18 p) -> canonical [0, p) without a Montgomery product: an under-estimate q of
+    // the quotient from the top limb alone (q <= floor(v / p), short by at most 4: see below), ONE row of NL multiply-adds for
+    // v - q p, then the three conditional subtractions of canonical_lt8p.  ~1/3 of the issue slots of mul(one) + canonical_lt2p;
+    // the NTT passes canonicalise every element of every sweep this way.
+    //   v >= top 2^(30 (NL-1)),  p < (ptop + 1) 2^(30 (NL-1))   =>   v / p > top / (ptop + 1) >= q   (never negative)
+    //   v / p - top / (ptop + 1) < (top + ptop + 1) / (ptop (ptop + 1)) + 1 < 2.5 for top < 2^26, ptop >= 2^13; the reciprocal
+    //   multiplication loses at most one more                                         =>   v - q p < 4.5 p < 8 p
+    G16_HD Fp30 canonical_quick() const {
+        constexpr uint32_t D = P::p30(NL - 1) + 1u;
+        static_assert(D > (1u << 13), "the top limb of p carries at least 14 bits for every supported field");
+        constexpr uint64_t MAGIC = ((uint64_t)1 << 40) / D;
+        const uint32_t q = (uint32_t)(((uint64_t)l[NL - 1] * MAGIC) >> 40);
+        Fp30 r;
+        int64_t carry = 0;
+        G16_UNROLL for (int i = 0; i < NL; ++i) {
+            const int64_t t = (int64_t)l[i] - (int64_t)((uint64_t)q * P::p30(i)) + carry;
+            r.l[i] = (i == NL - 1) ? (uint32_t)t : ((uint32_t)t & MASK);
+            carry = t >> 30;
+        }
+        return r.canonical_lt8p();
+    }
     // p - a for canonical a (a = 0 gives p: not canonical, but below 2p and harmless to the lazy arithmetic)
     G16_HD Fp30 neg_canonical() const {
         Fp30 d;

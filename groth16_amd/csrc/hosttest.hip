@@ -69,6 +69,22 @@ struct SelfTest {
     static int selftest_fr30(uint64_t seed, int iters) {
         typedef Fp30<typename Fr::Params> R30;
         uint64_t st = seed ^ 0xF7;
+        {   // canonical_quick at the edges: k p -> 0, k p - 1 -> p - 1, k p + 1 -> 1 for every k a pass can reach (and beyond)
+            R30 pl, kp = R30::zero();
+            for (int i = 0; i < R30::NL; ++i) pl.l[i] = Fr::Params::p30(i);
+            R30 pm1 = pl;
+            pm1.l[0] -= 1;   // p is odd: no borrow
+            R30 one_raw = R30::zero();
+            one_raw.l[0] = 1;
+            for (int k = 0; k <= 5000; ++k) {
+                if (k % 7 == 0 || k < 40 || (k & (k - 1)) == 0 || ((k + 1) & k) == 0) {
+                    if (!kp.canonical_quick().same_limbs(R30::zero())) return 520;
+                    if (!kp.add(pm1).canonical_quick().same_limbs(pm1)) return 521;
+                    if (!kp.add(one_raw).canonical_quick().same_limbs(one_raw)) return 522;
+                }
+                kp = kp.add(pl);
+            }
+        }
         for (int it = 0; it < iters; ++it) {
             Fr x = rand_fr(st), y = rand_fr(st), w = rand_fr(st);
             if (it == 0) { x = Fr::zero(); }
@@ -78,7 +94,18 @@ struct SelfTest {
             const Fr wt = R30::std_to_r30(w);
             const R30 w30 = R30::unpack(wt.v);
             auto canon = [](const R30& v) { Fr o; v.mul_impl(R30::one()).canonical_lt2p().pack(o.v); return o; };
+            // canonical_quick (the NTT passes' write-back) against the product with R' mod p, on every lazy value below
+            auto quick = [](const R30& v) { Fr o; v.canonical_quick().pack(o.v); return o; };
             if (!(canon(a.mul_impl(w30)) == x * w)) return 501;
+            if (!(quick(a.mul_impl(w30)) == x * w) || !(quick(a) == x) || !(quick(R30::zero()) == Fr::zero())) return 505;
+            {   // just below and at multiples of p, and the largest value a pass can hold (2^11 doublings of p - 1)
+                R30 m = R30::unpack((Fr::zero() - Fr::one()).v);   // p - 1
+                Fr want = Fr::zero() - Fr::one();
+                for (int k = 0; k < 12; ++k) {
+                    if (!(quick(m) == want) || !(quick(m.add(R30::unpack(Fr::one().v))) == want + Fr::one())) return 506;
+                    m = m.dbl(); want = want + want;
+                }
+            }
             // DIT butterfly chain: 11 stages without reduction
             R30 u = a, v = b;
             Fr ru = x, rv = y;
@@ -90,6 +117,7 @@ struct SelfTest {
                 u = nu; v = nv; ru = rnu; rv = rnv;
             }
             if (!(canon(u) == ru) || !(canon(v) == rv)) return 502;
+            if (!(quick(u) == ru) || !(quick(v) == rv)) return 507;
             // DIF butterfly chain: sums double every stage, subtraction adds 2^(k+1) p
             u = a; v = b; ru = x; rv = y;
             R30 s2 = a, d2 = b;
@@ -102,6 +130,7 @@ struct SelfTest {
                 u = nu; v = nu.add(nv).sub_pow2(nv, k + 1 < 12 ? k + 1 : 11);   // = nu, but with a grown bound
                 ru = rnu; rv = rnu;
                 if (!(canon(d2) == rnv)) return 503;
+                if (!(quick(d2) == rnv) || !(quick(nu) == rnu) || !(quick(v) == rnu)) return 508;
             }
             if (!(canon(s2) == ru)) return 504;
         }

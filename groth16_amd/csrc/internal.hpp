@@ -99,6 +99,12 @@ template <class C> int ntt_dif(const Domain<C>* d, typename C::Fr* data, bool in
 template <class C> int ntt_dit(const Domain<C>* d, typename C::Fr* data, bool inverse, const typename C::Fr* prescale, hipStream_t st);
 // ntt_dif(inverse = dif_inverse) then ntt_dit(inverse = !dif_inverse, prescale); the two innermost passes share one kernel
 template <class C> int ntt_dif_dit(const Domain<C>* d, typename C::Fr* data, bool dif_inverse, const typename C::Fr* prescale, hipStream_t st);
+// the same three over nbatch <= 3 arrays of one domain in ONE launch per sweep (the a, b, c chains of the witness map)
+template <class C> int ntt_dif_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, bool inverse, hipStream_t st);
+template <class C> int ntt_dit_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, bool inverse, const typename C::Fr* prescale,
+                                     hipStream_t st);
+template <class C> int ntt_dif_dit_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, bool dif_inverse,
+                                         const typename C::Fr* prescale, hipStream_t st);
 // out[k] = in[bitrev(k)] * table[k] * cst  (table may be null; has_cst selects the constant factor)
 template <class C> int bitrev_scale(const Domain<C>* d, typename C::Fr* out, const typename C::Fr* in, const typename C::Fr* table,
                                     const typename C::Fr* cst, hipStream_t st);
@@ -220,7 +226,9 @@ template <class F> int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, 
 template <class F> int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st);
 // the reductions of n <= 4 MSMs whose plans have the same bucket layout as ONE launch per stage (they fill the chip together
 // instead of each occupying a corner of it underneath the next MSM's bucket pass); G16_ERR_INTERNAL if the plans differ
-template <class F> int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st);
+// heavy_done: the heavy-bucket combines already ran (msm_heavy_reduce, one MSM at a time underneath the following pass)
+template <class F> int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st, bool heavy_done);
+template <class F> int msm_heavy_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st);
 // MSM bases are kept on the device in the bucket kernel's own Montgomery radix (x*R' with R' = 2^(30 NL), canonical,
 // packed in the usual words): converted in place, once, after upload (F = Fq for G1, Fq2 for G2).
 template <class F> int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st);
@@ -228,7 +236,10 @@ template <class F> int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t
 template <class F> XYZZ<F> fold_windows(const XYZZ<F>* window_sums, const MsmPlan& plan);
 // window tables for a merged plan: table[j * n + i] = 2^(c j) * src[i] for j < W, affine, in the bucket kernel's radix
 // (what convert_bases leaves); src holds standard-form affine points and is not modified
-template <class F> int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine<F>* d_table, hipStream_t st);
+// park: window_table_park_bytes<F>(n, W) of device scratch (rows waiting for the backward sweep of the shared inversion) that
+// stays valid until `st` has run the launches; nullptr = allocated inside, and the call returns with the table finished
+template <class F> int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine<F>* d_table, hipStream_t st, void* park = nullptr);
+template <class F> size_t window_table_park_bytes(uint64_t n, int W);
 
 // ---- CRS generation (setup.hip) -------------------------------------------------------------------
 template <class C>

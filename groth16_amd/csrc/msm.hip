@@ -524,7 +524,7 @@ __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(ReduceBatch
 // 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
 // ---------------------------------------------------------------------------------------------
 template <class F30>
-__global__ __launch_bounds__(RED_THREADS) void bucket_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t B, int W,
+__global__ __launch_bounds__(RED_THREADS, F30::LANES_PER_TASK == 1 ? 2 : 1) void bucket_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t B, int W,
                                                                     uint32_t G) {
     const AccRaw<typename F30::Raw>* __restrict__ partials = batch.partials[blockIdx.y];
     const uint32_t* __restrict__ slot_off = batch.slot_off[blockIdx.y];
@@ -924,25 +924,26 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
 }
 
 template <class F>
-int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st) {
+static int reduce_setup(size_t* lds_heavy, size_t* lds_win) {
     typedef typename Lazy30<F>::type F30;
     typedef AccRaw<typename F30::Raw> Raw;
-    if (n < 1 || n > REDUCE_BATCH) return G16_ERR_INTERNAL;
-    const MsmPlan& plan = sorts[0]->plan;
-    for (int i = 1; i < n; ++i)
-        if (sorts[i]->plan.B != plan.B || sorts[i]->plan.groups != plan.groups) return G16_ERR_INTERNAL;   // one launch = one plan
-    const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
-    const uint32_t cpw = plan.B / G;
     static PerDeviceOnce attr_once;
     std::atomic<bool>& attr_set = attr_once.flag();
-    const size_t lds_heavy = sizeof(Raw) * HEAVY_THREADS / F30::LANES_PER_TASK, lds_win = sizeof(Raw) * WIN_THREADS / F30::LANES_PER_TASK;
+    *lds_heavy = sizeof(Raw) * HEAVY_THREADS / F30::LANES_PER_TASK;
+    *lds_win = sizeof(Raw) * WIN_THREADS / F30::LANES_PER_TASK;
     if (!attr_set) {
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&heavy_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_heavy));
+                                        (int)*lds_heavy));
         G16_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_reduce_kernel<F30>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_win));
+                                        (int)*lds_win));
         attr_set = true;
     }
+    return G16_OK;
+}
+
+template <class F>
+static ReduceBatch<AccRaw<typename Lazy30<F>::type::Raw>, XYZZ<F>> make_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n) {
+    typedef AccRaw<typename Lazy30<F>::type::Raw> Raw;
     ReduceBatch<Raw, XYZZ<F>> batch;
     for (int i = 0; i < REDUCE_BATCH; ++i) {
         const int k = i < n ? i : 0;
@@ -952,8 +953,39 @@ int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* 
         batch.chunk_out[i] = static_cast<Raw*>(bufs[k]->chunk_out);
         batch.window_sums[i] = bufs[k]->window_sums;
     }
-    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, n), dim3(HEAVY_THREADS), lds_heavy, st, batch);
+    return batch;
+}
+
+// the cooperative combine of one MSM's heavy buckets alone (a few hundred workgroups at most: cheap enough to run underneath
+// the next bucket pass, which takes it off the batched reduction's chain)
+template <class F>
+int msm_heavy_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
+    typedef typename Lazy30<F>::type F30;
+    size_t lds_heavy, lds_win;
+    G16_TRY(reduce_setup<F>(&lds_heavy, &lds_win));
+    const MsmBuffers<F>* b = &buf;
+    const ScalarSort* s = &ss;
+    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, 1), dim3(HEAVY_THREADS), lds_heavy, st, make_reduce_batch<F>(&b, &s, 1));
     G16_LAUNCH_CHECK();
+    return G16_OK;
+}
+
+template <class F>
+int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st, bool heavy_done) {
+    typedef typename Lazy30<F>::type F30;
+    if (n < 1 || n > REDUCE_BATCH) return G16_ERR_INTERNAL;
+    const MsmPlan& plan = sorts[0]->plan;
+    for (int i = 1; i < n; ++i)
+        if (sorts[i]->plan.B != plan.B || sorts[i]->plan.groups != plan.groups) return G16_ERR_INTERNAL;   // one launch = one plan
+    const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
+    const uint32_t cpw = plan.B / G;
+    size_t lds_heavy, lds_win;
+    G16_TRY(reduce_setup<F>(&lds_heavy, &lds_win));
+    const auto batch = make_reduce_batch<F>(bufs, sorts, n);
+    if (!heavy_done) {
+        hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, n), dim3(HEAVY_THREADS), lds_heavy, st, batch);
+        G16_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, n), dim3(RED_THREADS), 0,
                        st, batch, plan.B, plan.groups, G);
     G16_LAUNCH_CHECK();
@@ -966,7 +998,7 @@ template <class F>
 int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
     const MsmBuffers<F>* b = &buf;
     const ScalarSort* s = &ss;
-    return msm_reduce_batch<F>(&b, &s, 1, st);
+    return msm_reduce_batch<F>(&b, &s, 1, st, false);
 }
 
 template <class F>
@@ -1029,15 +1061,24 @@ __global__ __launch_bounds__(TABLE_THREADS, 2) void build_window_tables_kernel(c
 }
 
 template <class F>
-int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine<F>* d_table, hipStream_t st) {
+size_t window_table_park_bytes(uint64_t n, int W) {
+    typedef typename Lazy30<F>::acc_type F30;
+    const uint64_t chunk = std::min(n ? n : 1, TABLE_CHUNK);
+    return (size_t)4 * (W > 1 ? W - 1 : 1) * TableLane<F30>::B::NL * chunk * F30::LANES_PER_TASK * sizeof(uint32_t);
+}
+
+// park: window_table_park_bytes<F>(n, W) of device scratch the caller keeps alive until the stream has run the launches (then
+// nothing here waits for the GPU: g16_pk_load queues the builds of all five queries behind one another and allocates the next
+// table while the previous one is being built); nullptr: allocated here, and the call returns with the table finished.
+template <class F>
+int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine<F>* d_table, hipStream_t st, void* park_buf) {
     typedef typename Lazy30<F>::acc_type F30;
     static_assert(sizeof(Affine<F>) == 2 * TableLane<F30>::PARTS * sizeof(typename TableLane<F30>::B::Std), "affine point = x parts | y parts");
     if (n == 0) return G16_OK;
     if (W > TABLE_MAX_W) return G16_ERR_INTERNAL;
     const uint64_t chunk = std::min(n, TABLE_CHUNK);
-    const size_t park_words = (size_t)4 * (W > 1 ? W - 1 : 1) * TableLane<F30>::B::NL * chunk * F30::LANES_PER_TASK;
-    uint32_t* park = nullptr;
-    if (hipMalloc((void**)&park, park_words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return G16_ERR_OOM; }
+    uint32_t* park = static_cast<uint32_t*>(park_buf);
+    if (!park && hipMalloc((void**)&park, window_table_park_bytes<F>(n, W)) != hipSuccess) { (void)hipGetLastError(); return G16_ERR_OOM; }
     int rc = G16_OK;
     for (uint64_t first = 0; first < n && rc == G16_OK; first += chunk) {
         const uint64_t count = std::min(chunk, n - first);
@@ -1046,9 +1087,10 @@ int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine
                            d_src, first, count, n, c, W, d_table, park);
         if (hipGetLastError() != hipSuccess) rc = G16_ERR_HIP;
     }
-    // the parking buffer is load-time scratch: wait for the chunks and give it back (g16_pk_load is synchronous anyway)
-    if (hipStreamSynchronize(st) != hipSuccess && rc == G16_OK) rc = G16_ERR_HIP;
-    (void)hipFree(park);
+    if (!park_buf) {
+        if (hipStreamSynchronize(st) != hipSuccess && rc == G16_OK) rc = G16_ERR_HIP;
+        (void)hipFree(park);
+    }
     return rc;
 }
 
@@ -1056,14 +1098,17 @@ int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine
     template int convert_bases<typename C::Fq>(Affine<typename C::Fq>*, uint64_t, hipStream_t);                             \
     template int convert_bases<typename C::Fq2>(Affine<typename C::Fq2>*, uint64_t, hipStream_t);                           \
     template int sort_scalars<C>(const typename C::Fr*, uint64_t, int, Arena&, hipStream_t, ScalarSort*);                   \
-    template int build_window_tables<typename C::Fq>(const Affine<typename C::Fq>*, uint64_t, int, int, Affine<typename C::Fq>*, hipStream_t);    \
-    template int build_window_tables<typename C::Fq2>(const Affine<typename C::Fq2>*, uint64_t, int, int, Affine<typename C::Fq2>*, hipStream_t); \
+    template int build_window_tables<typename C::Fq>(const Affine<typename C::Fq>*, uint64_t, int, int, Affine<typename C::Fq>*, hipStream_t, void*);    \
+    template int build_window_tables<typename C::Fq2>(const Affine<typename C::Fq2>*, uint64_t, int, int, Affine<typename C::Fq2>*, hipStream_t, void*); \
+    template size_t window_table_park_bytes<typename C::Fq>(uint64_t, int);                                                 \
+    template size_t window_table_park_bytes<typename C::Fq2>(uint64_t, int);                                                \
     template int msm_bucket_pass<typename C::Fq>(const Affine<typename C::Fq>*, int64_t, uint64_t, const ScalarSort&, Arena&, \
                                                  hipStream_t, MsmBuffers<typename C::Fq>*, EventTimer*);                      \
     template int msm_bucket_pass<typename C::Fq2>(const Affine<typename C::Fq2>*, int64_t, uint64_t, const ScalarSort&,     \
                                                   Arena&, hipStream_t, MsmBuffers<typename C::Fq2>*, EventTimer*);            \
     template int msm_reduce<typename C::Fq>(const MsmBuffers<typename C::Fq>&, const ScalarSort&, hipStream_t);             \
-    template int msm_reduce_batch<typename C::Fq>(const MsmBuffers<typename C::Fq>* const*, const ScalarSort* const*, int, hipStream_t); \
+    template int msm_reduce_batch<typename C::Fq>(const MsmBuffers<typename C::Fq>* const*, const ScalarSort* const*, int, hipStream_t, bool); \
+    template int msm_heavy_reduce<typename C::Fq>(const MsmBuffers<typename C::Fq>&, const ScalarSort&, hipStream_t);     \
     template int msm_reduce<typename C::Fq2>(const MsmBuffers<typename C::Fq2>&, const ScalarSort&, hipStream_t);           \
     template XYZZ<typename C::Fq> fold_windows<typename C::Fq>(const XYZZ<typename C::Fq>*, const MsmPlan&);               \
     template XYZZ<typename C::Fq2> fold_windows<typename C::Fq2>(const XYZZ<typename C::Fq2>*, const MsmPlan&);

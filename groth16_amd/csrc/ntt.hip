@@ -118,14 +118,21 @@ __device__ __forceinline__ void ntt30_round(uint32_t* lds, const Fp<P>* __restri
 }
 
 // One LDS-tiled pass over stages [s_lo, s_hi).  T = log2 of the contiguous run (ignored when s_lo == 0).
+// Up to three independent transforms over the same domain in ONE launch (blockIdx.y): the a, b, c chains of the witness map
+// (r1cs_to_qap.rs:201-207,220-221).  A sweep of one 2^22-point array is 2048 workgroups for 512 slots (and a rank's 2^19-point share
+// of the distributed map only 256); three chains per launch fill the chip and cut the launches of the six transforms to a third.
+template <class P>
+struct NttBatch { Fp<P>* p[3]; };
+
 template <class P, bool DIT>
-__global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(Fp<P>* __restrict__ data, const Fp<P>* __restrict__ tw,
+__global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(NttBatch<P> batch, const Fp<P>* __restrict__ tw,
                                                                  const Fp<P>* __restrict__ prescale, int log_n, int s_lo, int s_hi,
                                                                  int T) {
     typedef Fp30<P> F;
     constexpr int NL = F::NL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem);  // [NL][NTT_ROW]
+    Fp<P>* __restrict__ data = batch.p[blockIdx.y];
     const int K = s_hi - s_lo;
     const int TT = (s_lo == 0) ? 0 : T;
     const uint32_t E = 1u << (K + TT);
@@ -173,9 +180,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(Fp<P>* __restri
         __syncthreads();
         done += R;
     }
-    // ---- canonicalise (product with R' mod p brings any loosely reduced value below 1.1 p) and write back
+    // ---- canonicalise (Fp30::canonical_quick: quotient estimate from the top limb, one row of multiply-adds, three conditional
+    // subtractions -- a third of the issue slots of the product with R' mod p used until round 3) and write back
     for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
-        const F x = lds_load(e).mul_impl(F::one()).canonical_lt2p();
+        const F x = lds_load(e).canonical_quick();
         Fp<P> o;
         x.pack(o.v);
         data[gidx(e)] = o;
@@ -187,13 +195,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(Fp<P>* __restri
 // less per DIF/DIT pair (three pairs per witness map).  `prescale` is applied between the two (x lazy, < 2^K p: fine for
 // the product).
 template <class P>
-__global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(Fp<P>* __restrict__ data, const Fp<P>* __restrict__ tw_dif,
+__global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(NttBatch<P> batch, const Fp<P>* __restrict__ tw_dif,
                                                                     const Fp<P>* __restrict__ tw_dit, const Fp<P>* __restrict__ prescale,
                                                                     int log_n, int K) {
     typedef Fp30<P> F;
     constexpr int NL = F::NL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem);  // [NL][NTT_ROW]
+    Fp<P>* __restrict__ data = batch.p[blockIdx.y];
     const uint32_t E = 1u << K;
     const uint64_t base = (uint64_t)blockIdx.x << K;
     auto gidx = [&](uint32_t e) -> uint64_t { return base + e; };
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(Fp<P>* __res
         F x;
         G16_UNROLL for (int l = 0; l < NL; ++l) x.l[l] = lds[l * NTT_ROW + c];
         Fp<P> o;
-        x.mul_impl(F::one()).canonical_lt2p().pack(o.v);
+        x.canonical_quick().pack(o.v);
         data[base + e] = o;
     }
 }
@@ -295,7 +304,7 @@ static std::vector<PassPlan> plan_passes(int log_n) {
 }
 
 template <class P, bool DIT>
-static int launch_pass(Fp<P>* data, const Fp<P>* tw, const Fp<P>* prescale, int log_n, const PassPlan& pp, hipStream_t st) {
+static int launch_pass(const NttBatch<P>& batch, int nbatch, const Fp<P>* tw, const Fp<P>* prescale, int log_n, const PassPlan& pp, hipStream_t st) {
     const int K = pp.s_hi - pp.s_lo;
     const int TT = pp.s_lo == 0 ? 0 : pp.T;
     const size_t E = (size_t)1 << (K + TT);
@@ -308,48 +317,67 @@ static int launch_pass(Fp<P>* data, const Fp<P>* tw, const Fp<P>* prescale, int 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((ntt30_pass_kernel<P, DIT>), dim3((unsigned)blocks), dim3(NTT_THREADS), lds_bytes, st, data, tw, prescale, log_n,
-                       pp.s_lo, pp.s_hi, pp.T);
+    hipLaunchKernelGGL((ntt30_pass_kernel<P, DIT>), dim3((unsigned)blocks, (unsigned)nbatch), dim3(NTT_THREADS), lds_bytes, st, batch, tw, prescale,
+                       log_n, pp.s_lo, pp.s_hi, pp.T);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
 
 template <class C>
-int ntt_dif(const Domain<C>* d, typename C::Fr* data, bool inverse, hipStream_t st) {
-    typedef typename C::Fr::Params P;
-    if (d->log_n == 0) return G16_OK;
-    auto passes = plan_passes(d->log_n);
-    const typename C::Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
-    for (size_t i = passes.size(); i-- > 0;) G16_TRY((launch_pass<P, false>(data, tw, nullptr, d->log_n, passes[i], st)));
-    return G16_OK;
+static NttBatch<typename C::Fr::Params> make_batch(typename C::Fr* const* data, int nbatch) {
+    NttBatch<typename C::Fr::Params> b;
+    for (int i = 0; i < 3; ++i) b.p[i] = data[i < nbatch ? i : 0];
+    return b;
 }
 
 template <class C>
-int ntt_dit(const Domain<C>* d, typename C::Fr* data, bool inverse, const typename C::Fr* prescale, hipStream_t st) {
+int ntt_dif_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, bool inverse, hipStream_t st) {
     typedef typename C::Fr::Params P;
+    if (nbatch < 1 || nbatch > 3) return G16_ERR_INTERNAL;
+    if (d->log_n == 0) return G16_OK;
+    auto passes = plan_passes(d->log_n);
+    const typename C::Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
+    const NttBatch<P> b = make_batch<C>(data, nbatch);
+    for (size_t i = passes.size(); i-- > 0;) G16_TRY((launch_pass<P, false>(b, nbatch, tw, nullptr, d->log_n, passes[i], st)));
+    return G16_OK;
+}
+template <class C>
+int ntt_dif(const Domain<C>* d, typename C::Fr* data, bool inverse, hipStream_t st) { return ntt_dif_batch<C>(d, &data, 1, inverse, st); }
+
+template <class C>
+int ntt_dit_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, bool inverse, const typename C::Fr* prescale, hipStream_t st) {
+    typedef typename C::Fr::Params P;
+    if (nbatch < 1 || nbatch > 3) return G16_ERR_INTERNAL;
     if (d->log_n == 0) {
-        if (prescale) G16_TRY((scale_by_table<C>(data, prescale, 1, st)));
+        if (prescale) for (int i = 0; i < nbatch; ++i) G16_TRY((scale_by_table<C>(data[i], prescale, 1, st)));
         return G16_OK;
     }
     auto passes = plan_passes(d->log_n);
     const typename C::Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
+    const NttBatch<P> b = make_batch<C>(data, nbatch);
     for (size_t i = 0; i < passes.size(); ++i)
-        G16_TRY((launch_pass<P, true>(data, tw, i == 0 ? prescale : nullptr, d->log_n, passes[i], st)));
+        G16_TRY((launch_pass<P, true>(b, nbatch, tw, i == 0 ? prescale : nullptr, d->log_n, passes[i], st)));
     return G16_OK;
+}
+template <class C>
+int ntt_dit(const Domain<C>* d, typename C::Fr* data, bool inverse, const typename C::Fr* prescale, hipStream_t st) {
+    return ntt_dit_batch<C>(d, &data, 1, inverse, prescale, st);
 }
 
 // ntt_dif(inverse = dif_inverse) followed by ntt_dit(inverse = !dif_inverse, prescale), with the two innermost passes fused
 template <class C>
-int ntt_dif_dit(const Domain<C>* d, typename C::Fr* data, bool dif_inverse, const typename C::Fr* prescale, hipStream_t st) {
+int ntt_dif_dit_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, bool dif_inverse, const typename C::Fr* prescale, hipStream_t st) {
     typedef typename C::Fr::Params P;
+    if (nbatch < 1 || nbatch > 3) return G16_ERR_INTERNAL;
     if (d->log_n == 0) {
-        if (prescale) G16_TRY((scale_by_table<C>(data, prescale, 1, st)));
+        if (prescale) for (int i = 0; i < nbatch; ++i) G16_TRY((scale_by_table<C>(data[i], prescale, 1, st)));
         return G16_OK;
     }
     auto passes = plan_passes(d->log_n);
     const typename C::Fr* tw1 = dif_inverse ? d->tw_inv : d->tw_fwd;
     const typename C::Fr* tw2 = dif_inverse ? d->tw_fwd : d->tw_inv;
-    for (size_t i = passes.size(); i-- > 1;) G16_TRY((launch_pass<P, false>(data, tw1, nullptr, d->log_n, passes[i], st)));
+    const NttBatch<P> b = make_batch<C>(data, nbatch);
+    for (size_t i = passes.size(); i-- > 1;) G16_TRY((launch_pass<P, false>(b, nbatch, tw1, nullptr, d->log_n, passes[i], st)));
     {
         const int K = passes[0].s_hi;
         const size_t blocks = ((size_t)1 << d->log_n) >> K;
@@ -361,12 +389,16 @@ int ntt_dif_dit(const Domain<C>* d, typename C::Fr* data, bool dif_inverse, cons
                                             (int)lds_bytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL((ntt30_dif_dit_kernel<P>), dim3((unsigned)blocks), dim3(NTT_THREADS), lds_bytes, st, data, tw1, tw2, prescale,
+        hipLaunchKernelGGL((ntt30_dif_dit_kernel<P>), dim3((unsigned)blocks, (unsigned)nbatch), dim3(NTT_THREADS), lds_bytes, st, b, tw1, tw2, prescale,
                            d->log_n, K);
         G16_LAUNCH_CHECK();
     }
-    for (size_t i = 1; i < passes.size(); ++i) G16_TRY((launch_pass<P, true>(data, tw2, nullptr, d->log_n, passes[i], st)));
+    for (size_t i = 1; i < passes.size(); ++i) G16_TRY((launch_pass<P, true>(b, nbatch, tw2, nullptr, d->log_n, passes[i], st)));
     return G16_OK;
+}
+template <class C>
+int ntt_dif_dit(const Domain<C>* d, typename C::Fr* data, bool dif_inverse, const typename C::Fr* prescale, hipStream_t st) {
+    return ntt_dif_dit_batch<C>(d, &data, 1, dif_inverse, prescale, st);
 }
 
 template <class C>
@@ -468,6 +500,9 @@ void domain_destroy(Domain<C>* d) {
     template int ntt_dif<C>(const Domain<C>*, typename C::Fr*, bool, hipStream_t);                                 \
     template int ntt_dit<C>(const Domain<C>*, typename C::Fr*, bool, const typename C::Fr*, hipStream_t);          \
     template int ntt_dif_dit<C>(const Domain<C>*, typename C::Fr*, bool, const typename C::Fr*, hipStream_t);      \
+    template int ntt_dif_batch<C>(const Domain<C>*, typename C::Fr* const*, int, bool, hipStream_t);              \
+    template int ntt_dit_batch<C>(const Domain<C>*, typename C::Fr* const*, int, bool, const typename C::Fr*, hipStream_t);   \
+    template int ntt_dif_dit_batch<C>(const Domain<C>*, typename C::Fr* const*, int, bool, const typename C::Fr*, hipStream_t); \
     template int bitrev_scale<C>(const Domain<C>*, typename C::Fr*, const typename C::Fr*, const typename C::Fr*,  \
                                  const typename C::Fr*, hipStream_t);                                              \
     template int scale_by_table<C>(typename C::Fr*, const typename C::Fr*, size_t, hipStream_t);                   \

@@ -80,10 +80,9 @@ int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, ty
     G16_LAUNCH_CHECK();
     // ntt_timers (optional, two of them): the six transforms of :201-207,220-221, then the seventh (:232) with its un-permute
     if (ntt_timers) G16_TRY(ntt_timers[0].start(st));
-    for (int m = 0; m < 3; ++m) {
-        // ifft then coset fft (r1cs_to_qap.rs:201-207): inverse DIF, n^-1 g^bitrev(i), forward DIT
-        G16_TRY((ntt_dif_dit<C>(dom, outs[m], /*dif_inverse=*/true, dom->s1_br, st)));
-    }
+    // ifft then coset fft of a, b, c (r1cs_to_qap.rs:201-207, 220-221): inverse DIF, n^-1 g^bitrev(i), forward DIT -- the three
+    // chains in one launch per sweep
+    G16_TRY((ntt_dif_dit_batch<C>(dom, outs, 3, /*dif_inverse=*/true, dom->s1_br, st)));
     if (ntt_timers) G16_TRY(ntt_timers[0].stop(st));
     hipLaunchKernelGGL((quotient_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, c, dom->zinv, n);
     G16_LAUNCH_CHECK();
@@ -237,10 +236,8 @@ int dwm_stage(const DeviceCircuit<C>* ck, const DistWm<C>* d, int stage, const t
         hipLaunchKernelGGL((spmv3_kernel<Fr>), dim3((unsigned)((M + 255) / 256), 3), dim3(256), 0, st, args, d_z, ck->num_inputs,
                            ck->num_constraints, (uint64_t)d->rank, (uint64_t)d->world, (uint64_t)M, dm->log_n);
         G16_LAUNCH_CHECK();
-        for (int m = 0; m < 3; ++m) {
-            G16_TRY((ntt_dit<C>(dm, work[m], /*inverse=*/true, nullptr, st)));
-            G16_TRY((scale_by_table<C>(work[m], d->tw1, M, st)));
-        }
+        G16_TRY((ntt_dit_batch<C>(dm, work, 3, /*inverse=*/true, nullptr, st)));
+        for (int m = 0; m < 3; ++m) G16_TRY((scale_by_table<C>(work[m], d->tw1, M, st)));
         return G16_OK;
     }
     if (stage == 1) {
@@ -251,7 +248,7 @@ int dwm_stage(const DeviceCircuit<C>* ck, const DistWm<C>* d, int stage, const t
     if (stage == 2) {
         // the received chunks are x[ib], ib natural: M-point transform with w_M (bit-reversed out), pointwise
         // (a b - c) / Z(g) (r1cs_to_qap.rs:209, 223-230; any common order works), then the last transform's type-1 half
-        for (int m = 0; m < 3; ++m) G16_TRY((ntt_dif<C>(dm, recv[m], /*inverse=*/false, st)));
+        G16_TRY((ntt_dif_batch<C>(dm, recv, 3, /*inverse=*/false, st)));
         hipLaunchKernelGGL((quotient_kernel<Fr>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, recv[0], recv[1], recv[2], d->zinv, M);
         G16_LAUNCH_CHECK();
         G16_HIP_TRY(hipMemcpyAsync(work[0], recv[0], M * sizeof(Fr), hipMemcpyDeviceToDevice, st));

@@ -87,8 +87,9 @@ def msm_path(request, monkeypatch):
     bucket set is cut into 2 / 16 classes (the shape a 2^22 key uses) even at test sizes.  The library reads the
     variables at call time."""
     name = request.param
-    # "..._affineR": R levels of batched-affine pairwise additions in front of the XYZZ bucket pass (the default for keys of
-    # 2^20 points and more; forced here so that holes, tangents, cancellations and identity bases run through it at test sizes)
+    # "..._affineR": R levels of batched-affine pairwise additions in front of the XYZZ bucket pass.  OPT-IN and OFF by default
+    # (make_msm_plan sets affine_levels = 0 unless G16_MSM_AFFINE_LEVELS is set: the levels measured slower, DESIGN.md 4.3);
+    # forced here so that holes, tangents, cancellations and identity bases keep running through the path at test sizes
     monkeypatch.setenv("G16_MSM_AFFINE_LEVELS", name[-1] if "_affine" in name else "0")
     name = name.split("_affine")[0]
     if name != "per_window":

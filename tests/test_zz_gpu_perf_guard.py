@@ -10,7 +10,15 @@ import time
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+# Own marker: wall-time bounds do not belong in the correctness tier (-m gpu) -- a shared or throttled box would fail a run whose
+# results are fine.  Run with `pytest -m perf` on the GPU box.
+def _no_gpu():
+    import torch
+
+    return not torch.cuda.is_available()
+
+
+pytestmark = [pytest.mark.perf, pytest.mark.skipif(_no_gpu(), reason="needs a visible MI355X")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
