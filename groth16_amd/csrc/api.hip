@@ -421,12 +421,16 @@ struct Impl {
         G16_TRY(ctx->t_wm.start(s1));
         if (h_ext) {
             // h comes from the distributed map: whatever g16_dwm_stage_async (and the caller's exchanges) enqueued on the
-            // witness-map stream must have finished before h is read -- by the h sort and the h MSM only; the witness sort and
-            // the four h-independent passes below start at once
+            // witness-map stream must have finished before h is read.  The witness sort (stream 2) does NOT wait for it and runs
+            // beside the map's stages and exchanges.  The bucket passes DO wait: the map is a chain of ~25 short dependent
+            // kernels and 7 exchanges, and a kernel launched while a bucket pass holds every wave slot starts only when that
+            // pass's workgroups retire -- underneath back-to-back passes each link of the chain would cost a whole pass (the
+            // starvation measured on the single-GPU schedule: 60 ms for a 6 ms map).  So: map and sort side by side, then passes.
             d_h = const_cast<Fr*>(h_ext);
             ctx->t_ntt[0].used = ctx->t_ntt[1].used = false;
             G16_HIP_TRY(hipEventRecord(ctx->ev_dwm, ctx->stream_wm));
             G16_HIP_TRY(hipStreamWaitEvent(s3, ctx->ev_dwm, 0));
+            G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_dwm, 0));
         } else {
             G16_TRY(ctx->arena.alloc_n(n, &d_h));
             G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1, ctx->t_ntt)));

@@ -183,8 +183,9 @@ int g16_dwm_stage(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assi
                   uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local);
 /* The same stages WITHOUT host synchronisation: the stage is enqueued on the context's witness-map stream (g16_ctx_wm_stream) and the
  * call returns; the caller enqueues its exchange on that SAME stream (e.g. torch.cuda.ExternalStream), so stages and exchanges are
- * ordered by the stream alone.  full_assignment must be device memory.  A following g16_prove_partial_h orders its h sort / h MSM
- * after everything enqueued on that stream; its witness sort and the four h-independent MSMs (prover.rs:74,92,105,113) do not wait. */
+ * ordered by the stream alone.  full_assignment must be device memory.  A following g16_prove_partial_h orders its h sort and its
+ * bucket passes after everything enqueued on that stream; its witness digit/sort pass (shared by the MSMs of prover.rs:74,92,105,
+ * 113) does not wait and runs beside the map's stages and exchanges. */
 void* g16_ctx_wm_stream(g16_ctx* ctx);
 int g16_dwm_stage_async(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assignment_dev, uint64_t n_assign,
                         uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local);

@@ -12,6 +12,7 @@
 #                         pass; tools/pmc_summary.py traffic -> pmc_traffic_calibrated.json
 #   pmcsq                 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY of bench.py --steps 2
 #   sim8 [log2]           bench.py --sim-shards 8 --log2 <22>; with rocprofv3 kernel stats
+#   trace [single|sim8]   rocprofv3 --kernel-trace of a few proofs -> kernel_trace_<what>.csv + the last proof's timeline
 #   ubench                tools/bin/ubench_* (instruction issue rates, accumulate probes)
 set -u
 TAG=$1; shift
@@ -96,6 +97,12 @@ PY
       timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_sim -o st --output-format csv -- python bench.py --sim-shards 8 --log2 $k --steps 8 --warmup 3 \
         > $O/sim8_k${k}_prof.json 2> $O/sim8_k${k}_prof.err
       find $O/prof_sim -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/sim8_k${k}_kernel_stats.csv; rm -rf $O/prof_sim ;;
+    trace)   # per-kernel start / end timestamps of a few proofs (kernel trace only): tools/trace_timeline.py prints the timeline
+      what=single; if [ $# -gt 0 ] && [[ "$1" == sim8 || "$1" == single ]]; then what=$1; shift; fi
+      if [ $what = sim8 ]; then cmd="python bench.py --sim-shards 8 --log2 22 --steps 3 --warmup 2"; else cmd="python bench.py --steps 2 --warmup 2 --no-cpu-baseline"; fi
+      timeout 600 rocprofv3 --kernel-trace -d $O/prof_trace_$what -o tr --output-format csv -- $cmd > $O/trace_$what.json 2> $O/trace_$what.err; echo "trace $what rc=$?"
+      find $O/prof_trace_$what -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $O/kernel_trace_$what.csv; rm -rf $O/prof_trace_$what
+      python tools/trace_timeline.py $O/kernel_trace_$what.csv | tail -120 ;;
     ubench)
       for b in tools/bin/ubench_*; do timeout 200 $b > $O/$(basename $b).txt 2>&1; grep -h "PROBE" $O/$(basename $b).txt | head -12; done ;;
     *) echo "unknown step $step"; exit 2 ;;
