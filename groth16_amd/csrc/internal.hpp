@@ -166,7 +166,7 @@ struct MsmPlan {
     int groups = 0;
     bool merged = false;
     uint32_t B = 0;     // buckets per group
-    uint32_t Lmax = 0;  // segment length: entries one bucket-pass lane walks (power of two)
+    uint32_t Lmax = 0;  // segment length: entries one bucket-pass lane walks (any integer >= 8)
     // Batched-affine plan (batch_affine.hpp): R > 0 pads every bucket region of the sorted list to a multiple of 2^R entries
     // (holes = the identity); R levels of pairwise affine additions with one shared inversion per lane batch then shrink the
     // list 2^R-fold before the XYZZ bucket pass walks what is left (<= ceil(m / 2^R) points per bucket of m entries).

@@ -303,12 +303,12 @@ static __global__ __launch_bounds__(SCAN_THREADS) void scan_write_kernel(const u
 
 // partial-sum slots of bucket b = number of length-L segments of the sorted list its entries touch
 // (batched-affine plan: the bucket pass walks the level-R list, whose bucket regions are offsets >> R)
-static __global__ void bucket_slots_kernel(const uint32_t* __restrict__ offsets, uint32_t M, uint32_t off_shift, uint32_t lseg_log,
+static __global__ void bucket_slots_kernel(const uint32_t* __restrict__ offsets, uint32_t M, uint32_t off_shift, uint32_t lseg,
                                     uint32_t* __restrict__ nparts, uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= M) return;
     const uint32_t lo = offsets[b] >> off_shift, hi = offsets[b + 1] >> off_shift;
-    const uint32_t np = hi > lo ? (((hi - 1) >> lseg_log) - (lo >> lseg_log) + 1u) : 0u;
+    const uint32_t np = hi > lo ? ((hi - 1) / lseg - lo / lseg + 1u) : 0u;
     nparts[b] = np;
     if (np > HEAVY_PARTS) heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
 }
@@ -360,14 +360,14 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(con
 template <class F30, bool DIRECT>
 __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(
     const Affine<typename F30::Std>* __restrict__ bases, int64_t shift, uint64_t base_count, const uint32_t* __restrict__ sorted,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ slot_off, uint32_t M, uint32_t off_shift, uint32_t lseg_log,
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ slot_off, uint32_t M, uint32_t off_shift, uint32_t lseg,
     uint32_t merged, AccRaw<typename F30::Raw>* __restrict__ partials) {
     const uint32_t t = (blockIdx.x * ACC_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
     const uint32_t S = offsets[M] >> off_shift;                                            // entries in total
-    const uint64_t start64 = (uint64_t)t << lseg_log;
+    const uint64_t start64 = (uint64_t)t * lseg;
     if (start64 >= S) return;
     const uint32_t start = (uint32_t)start64;
-    const uint32_t end = (uint32_t)min((uint64_t)S, start64 + (1u << lseg_log));
+    const uint32_t end = (uint32_t)min((uint64_t)S, start64 + lseg);
     uint32_t lo = 0, hi = M;  // bucket containing `start`: offsets[lo] <= start < offsets[lo + 1]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
     uint32_t v_fetch = DIRECT ? start + 1 : (start + 1 < end ? sorted[start + 1] : 0u);   // entry e+1's word, loaded one iteration early
     for (uint32_t e = start; e < end; ++e) {
         if (e == b_end) {  // crossed into the next non-empty bucket: flush this segment's share of bucket b
-            acc.store_raw(&partials[slot_off[b] + (t - (b_first >> lseg_log))]);
+            acc.store_raw(&partials[slot_off[b] + (t - b_first / lseg)]);
             acc = Acc30<F30>::identity();
             do { ++b; b_end = offsets[b + 1] >> off_shift; } while (b_end <= e);
             b_first = offsets[b] >> off_shift;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         }
         if constexpr (!F30::ACC_PREFETCH) advance();
     }
-    acc.store_raw(&partials[slot_off[b] + (t - (b_first >> lseg_log))]);
+    acc.store_raw(&partials[slot_off[b] + (t - b_first / lseg)]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -708,19 +708,32 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
         plan->affine_levels = R;
     }
     const uint64_t entries = (all_entries >> plan->affine_levels) + (plan->affine_levels ? plan->buckets() : 0);   // what the bucket pass walks
-    // segment length of the bucket pass: 64 entries per lane (a pass ends with one partly filled round of segments, ~1/2
-    // segment time on average: 64 measured 1 % faster than 128 at 2^22, 256 is 13 % slower, 32 drowns in partial sums),
-    // shorter for small inputs so that the pass still has >= ~4 segments per lane slot of the chip
-    // (256 CUs x 4 SIMDs x 2 waves x 64 lanes)
-    uint32_t l = 64;
-    while (l > 16 && entries / l < 4ull * 131072ull) l >>= 1;
+    // Segment length of the bucket pass (entries one lane walks; any integer).  The pass is one launch of ceil(entries / L) lanes
+    // over 131072 lane slots (256 CUs x 4 SIMDs x 2 waves x 64 lanes; a G2 lane pair takes two, so G2 rounds = 2 x G1 rounds),
+    // every lane does the same L additions, so the launch takes ceil(rounds) x L addition-times: a power-of-two L wastes the unfilled
+    // part of the last round (2^22 constraints: L = 64 -> 6.5 rounds, 7 paid; an 8-way shard: L = 16 -> 3.5 rounds, 4 paid: 13 %).
+    // L is chosen so that the rounds come out (just under) an integer -- k rounds of L = ceil(entries / (slots k)) -- with k such that L
+    // stays near 70: long enough that a bucket of the mean load touches few segments (each touched segment costs the reduction one
+    // full addition), short enough for several rounds to even out the lanes that flush more buckets than others.
+    uint32_t l = 16;
+    {
+        const double per_slot = (double)entries / 131072.0;
+        if (per_slot > 16.0) {
+            int k = (int)(per_slot / 72.0 + 0.5);
+            if (k < 1) k = 1;
+            l = (uint32_t)((per_slot + k - 1e-9) / k);      // ceil(per_slot / k) for non-integers, per_slot / k when it divides
+            if ((double)l * k < per_slot) ++l;
+            if (l < 16) l = 16;
+            if (l > 160) l = 160;
+        }
+    }
     // ... but never much shorter than the mean bucket load: a bucket of ~mean entries then touches at most ~5 segments and
     // stays below the heavy-bucket threshold (otherwise EVERY bucket would go through the cooperative combine)
     const uint64_t mean = entries / plan->buckets() + 1;
     while (l < 128 && (uint64_t)l * 4 < mean) l <<= 1;
-    if (const char* e = getenv("G16_MSM_SEGMENT")) {   // experiments: force the segment length (power of two, 16..1024)
+    if (const char* e = getenv("G16_MSM_SEGMENT")) {   // experiments: force the segment length (8 .. 4096)
         const int v = atoi(e);
-        if (v >= 16 && v <= 1024 && (v & (v - 1)) == 0) l = (uint32_t)v;
+        if (v >= 8 && v <= 4096) l = (uint32_t)v;
     }
     plan->Lmax = l;
     // histogram / scatter chunking: ~2048 workgroups in total, chunk a multiple of 1024 points
@@ -800,7 +813,6 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     }
     const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
     const uint32_t blog = (uint32_t)ilog2(plan.B);
-    const uint32_t lseg_log = (uint32_t)ilog2(plan.Lmax);
     const uint32_t max_scan = std::max(M, plan.merged ? Q * nb : 0u);
     G16_TRY(arena.alloc_n((size_t)(max_scan + SCAN_TILE - 1) / SCAN_TILE, &block_sums));
     auto prefix_scan = [&](const uint32_t* vals, uint32_t* prefix, uint32_t count, uint32_t padmask = 0) -> int {
@@ -833,7 +845,7 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
         G16_LAUNCH_CHECK();
     }
     G16_TRY(prefix_scan(counts, out->offsets, M, pad));
-    hipLaunchKernelGGL(bucket_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, out->offsets, M, (uint32_t)R, lseg_log, nparts,
+    hipLaunchKernelGGL(bucket_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, out->offsets, M, (uint32_t)R, plan.Lmax, nparts,
                        out->heavy);
     G16_LAUNCH_CHECK();
     G16_TRY(prefix_scan(nparts, out->task_off, M));
@@ -913,10 +925,10 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
         const dim3 grid((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS));
         if (R)
             hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, true>), grid, dim3(ACC_THREADS), 0, st, walk, (int64_t)0, (uint64_t)0,
-                               (const uint32_t*)nullptr, ss.offsets, ss.task_off, M, (uint32_t)R, (uint32_t)ilog2(plan.Lmax), 0u, partials);
+                               (const uint32_t*)nullptr, ss.offsets, ss.task_off, M, (uint32_t)R, plan.Lmax, 0u, partials);
         else
             hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, false>), grid, dim3(ACC_THREADS), 0, st, d_bases, shift, base_count, ss.sorted,
-                               ss.offsets, ss.task_off, M, 0u, (uint32_t)ilog2(plan.Lmax), plan.merged ? 1u : 0u, partials);
+                               ss.offsets, ss.task_off, M, 0u, plan.Lmax, plan.merged ? 1u : 0u, partials);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));

@@ -110,6 +110,26 @@ def test_msm_matches_oracle(env, orc, g2, n, msm_path):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("seg", [8, 19, 60, 70, 139])
+@pytest.mark.parametrize("g2", [False, True])
+@pytest.mark.parametrize("merged", [False, True])
+def test_msm_any_segment_length(env, orc, g2, merged, seg, monkeypatch):
+    """the bucket pass walks segments of ANY length (round 3: the length is chosen so that the launch fills whole rounds of the
+    chip, e.g. 70 at 2^22 constraints, 56 for an 8-way shard): odd lengths, lengths above and below the mean bucket load, with
+    repeated scalars so that buckets span many segments (heavy-bucket path) -- result == oracle"""
+    monkeypatch.setenv("G16_MSM_SEGMENT", str(seg))
+    if merged:
+        monkeypatch.setenv("G16_MSM_API_PRECOMP", "1")
+    curve, prover = env
+    n = 5000
+    bases = orc.synth_bases(curve, g2, 5, n)
+    sc = orc.rand_fr(curve, 40 + seg, n)
+    sc[100:2100] = sc[100]          # 2000 equal scalars: every window gets one bucket of 2000 entries
+    bases[50:400:9] = 0
+    got = prover.msm(bases, sc, g2)
+    assert (got == orc.msm(curve, g2, bases, sc)).all()
+
+
 @pytest.mark.parametrize("g2", [False, True])
 def test_msm_adversarial_inputs(env, orc, g2, msm_path):
     """zero scalars, r-1, all-equal scalars (benches/bench.rs:52-54 shape), identity bases, repeated
