@@ -1040,7 +1040,14 @@ static bool dist_wm_admissible(int world, uint64_t domain) {
     return domain % ((uint64_t)world * (uint64_t)world) == 0;
 }
 
-static bool devices_repeat(const g16_ctx* ctx) {
+// A context may list one physical device several times (tests: N shards on the one GPU of the box).  Until round 3 the LOAD paths
+// of such a context ran one after the other: n concurrent window-table builds on sibling queues of one device had aborted inside
+// the HIP runtime in the full test suite (never in isolation).  Those kernels asked for 9-17 KB of scratch per lane; the builders
+// were rewritten without per-lane arrays (window_tables.hpp: <= 208 B), which removes the one thing that set these launches apart,
+// so the loads run concurrently again.  G16_MULTI_SERIAL_LOAD=1 brings the serial order back.
+static bool serial_loads(const g16_ctx* ctx) {
+    const char* e = getenv("G16_MULTI_SERIAL_LOAD");
+    if (!e || atoi(e) == 0) return false;
     for (size_t a = 0; a < ctx->subs.size(); ++a)
         for (size_t b = a + 1; b < ctx->subs.size(); ++b)
             if (ctx->subs[a]->device == ctx->subs[b]->device) return true;
@@ -1235,7 +1242,7 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
             v.h = cut(view->h, h_lo, h_hi, g1b);
             if (dist_h) { v.h.points = hblock.data(); v.h.count = hblock.size() / g1b; v.h.start = 0; }
             return g16_pk_load(ctx->subs[(size_t)i], &v, &h->subs[(size_t)i]);
-        }, devices_repeat(ctx));
+        }, serial_loads(ctx));
         if (rc) { g16_pk_free(h); return rc; }
         *out = h;
         return G16_OK;
@@ -1267,7 +1274,7 @@ int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_input
         h->subs.assign((size_t)n, nullptr);
         const int rc = for_each_device(n, [&](int i) -> int {
             return g16_circuit_load(ctx->subs[(size_t)i], abc, num_inputs, num_constraints, num_variables, &h->subs[(size_t)i]);
-        }, devices_repeat(ctx));
+        }, serial_loads(ctx));
         if (rc) { g16_circuit_free(h); return rc; }
         h->domain_size = h->subs[0]->domain_size;
         h->num_variables = num_variables;
@@ -1283,7 +1290,7 @@ int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_input
                 if (hipMalloc((void**)&sl.h_local, M * 32) != hipSuccess || hipMalloc((void**)&sl.z_dev, (num_variables ? num_variables : 1) * 32) != hipSuccess)
                     return G16_ERR_OOM;
                 return G16_OK;
-            }, devices_repeat(ctx));
+            }, serial_loads(ctx));
             if (rc2) { g16_circuit_free(h); return rc2; }
         }
         *out = h;

@@ -708,25 +708,14 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
         plan->affine_levels = R;
     }
     const uint64_t entries = (all_entries >> plan->affine_levels) + (plan->affine_levels ? plan->buckets() : 0);   // what the bucket pass walks
-    // Segment length of the bucket pass (entries one lane walks; any integer).  The pass is one launch of ceil(entries / L) lanes
-    // over 131072 lane slots (256 CUs x 4 SIMDs x 2 waves x 64 lanes; a G2 lane pair takes two, so G2 rounds = 2 x G1 rounds),
-    // every lane does the same L additions, so the launch takes ceil(rounds) x L addition-times: a power-of-two L wastes the unfilled
-    // part of the last round (2^22 constraints: L = 64 -> 6.5 rounds, 7 paid; an 8-way shard: L = 16 -> 3.5 rounds, 4 paid: 13 %).
-    // L is chosen so that the rounds come out (just under) an integer -- k rounds of L = ceil(entries / (slots k)) -- with k such that L
-    // stays near 70: long enough that a bucket of the mean load touches few segments (each touched segment costs the reduction one
-    // full addition), short enough for several rounds to even out the lanes that flush more buckets than others.
-    uint32_t l = 16;
-    {
-        const double per_slot = (double)entries / 131072.0;
-        if (per_slot > 16.0) {
-            int k = (int)(per_slot / 72.0 + 0.5);
-            if (k < 1) k = 1;
-            l = (uint32_t)((per_slot + k - 1e-9) / k);      // ceil(per_slot / k) for non-integers, per_slot / k when it divides
-            if ((double)l * k < per_slot) ++l;
-            if (l < 16) l = 16;
-            if (l > 160) l = 160;
-        }
-    }
+    // Segment length of the bucket pass (entries one lane walks; the kernels take any integer >= 8): 64 entries per lane,
+    // shorter for small inputs so that the pass still has >= ~4 segments per lane slot of the chip (256 CUs x 4 SIMDs x 2 waves x 64
+    // lanes).  Measured at 2^22 (profiles/r03_ab_segment_length.txt, one box): 60 and 64 tie, 70 / 84 +0.8 %, 104 +1.2 %, 139 +3 %;
+    // for an 8-way shard 16 and 19 tie, 28 +2 %, 56 (ONE full round of the chip) +6 %.  Lanes do not take equal time (a lane that
+    // crosses more bucket boundaries flushes more partial sums), workgroups are re-dispatched one by one as others retire, so many
+    // short segments balance better than few long ones, and "fill whole rounds of the chip" -- tried in round 3 -- does not pay.
+    uint32_t l = 64;
+    while (l > 16 && entries / l < 4ull * 131072ull) l >>= 1;
     // ... but never much shorter than the mean bucket load: a bucket of ~mean entries then touches at most ~5 segments and
     // stays below the heavy-bucket threshold (otherwise EVERY bucket would go through the cooperative combine)
     const uint64_t mean = entries / plan->buckets() + 1;

@@ -138,7 +138,11 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out);
  * over xGMI) and g16_pk_load gathers every h_query shard in the block order that leaves h in (the key must then be the
  * circuit's: h_query holds domain_size - 1 bases, generator.rs:168; anything else is G16_ERR_BAD_LENGTH at g16_prove).  g16_prove_partial is the per-device form and is refused on such a context;
  * g16_prove_finalize and the unit-level entry points run on the first device.  device_ids may repeat.  n_dev == 1 is
- * g16_ctx_create. */
+ * g16_ctx_create.
+ * EXPERIMENTAL for n_dev > 1 over distinct devices: every test so far ran with one physical GPU listed several times (the build
+ * pool has one-GPU boxes), so peer access, hipMemcpyPeerAsync between devices and the cross-device event waits of g16_prove have
+ * not met real hardware; tests/test_gpu_parity.py::test_multi_device_context_distinct_gpus runs wherever >= 2 GPUs are visible.
+ * The process-per-GPU form (g16_prove_partial + one all-gather, bench.py --gpus N) is the supported multi-GPU path. */
 int g16_ctx_create_multi(int curve, const int* device_ids, int n_dev, g16_ctx** out);
 int g16_ctx_num_devices(const g16_ctx* ctx);
 void g16_ctx_destroy(g16_ctx* ctx);

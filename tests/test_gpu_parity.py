@@ -349,6 +349,28 @@ def test_multi_device_context_single_call(orc, g, curve, n_dev):
         assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_multi_device_context_distinct_gpus(orc, g, curve):
+    """the multi-device context over DISTINCT physical GPUs (peer access, hipMemcpyPeerAsync between devices, cross-device event
+    waits, concurrent per-device key loads) -- skipped on a one-GPU box, which is all the build pool offers: until this has passed
+    on real hardware the multi-device context is EXPERIMENTAL (include/g16_mi355x.h says so)."""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    ids = list(range(min(ndev, 8)))
+    ids = ids[: 1 << (len(ids).bit_length() - 1)]          # a power of two: the distributed witness map
+    ck = orc.syn_circuit(curve, 12, 16)
+    pk, _ = orc.setup(ck, 4)
+    gm, gp = mats_of(g, ck), pk_of(g, pk)
+    for devs in (ids, ids[:3] if len(ids) > 2 else ids):     # distributed map; replicated map (3 devices)
+        with g.Groth16(curve, devs) as prover:
+            for r, s in ((orc.rand_fr(curve, 91, 1)[0], orc.rand_fr(curve, 92, 1)[0]), (np.zeros(4, dtype=np.uint64), orc.rand_fr(curve, 93, 1)[0])):
+                proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
+                assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+
+
 def test_multi_device_context_padded_domain(orc, g):
     """a circuit whose domain is padded (MiMC: nc + num_inputs not a power of two) through the distributed path of the
     multi-device context, and a key that does not belong to the circuit's domain is refused"""

@@ -63,6 +63,7 @@ while [ $# -gt 0 ]; do
       done
       python tools/pmc_summary.py traffic $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/calib_FETCH_SIZE.jsonl > $O/pmc_traffic_calibrated.json
       rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+      python tools/make_pmc_traffic.py $O/pmc_traffic_calibrated.json bls12_381 22 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/bin/calib and of bench.py --steps 2 --warmup 1, tools/gpu_session.sh pmc" > $O/pmc_traffic.json
       python - $O/pmc_traffic_calibrated.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
