@@ -70,12 +70,13 @@ struct g16_ctx {
     hipStream_t stream_wm = nullptr;   // g16_dwm_stage_async: the distributed witness map's stages (and the caller's exchanges between them)
     hipEvent_t ev_dwm = nullptr;
     hipEvent_t ev_heavy[4] = {};   // G1 MSM k's heavy-bucket combine (side stream) done
+    hipEvent_t ev_edge[8] = {};    // timestamps on stream 1 at the boundaries of the bucket passes (see prove_partial)
     hipStream_t red[5];   // one stream per MSM for its reductions: they are chains of dependent additions in a few waves
                           // (G2: ~9 ms), so five of them side by side end sooner than one after the other
     Arena arena;
     g16_timings tm;
     EventTimer t_wm, t_prep_h, t_prep_z, t_bucket[5], t_ntt[2];
-    hipEvent_t ev_z = nullptr, ev_h = nullptr, ev_wm = nullptr, ev_acc[5] = {}, ev_done[5] = {}, ev_msm_start[5] = {};
+    hipEvent_t ev_z = nullptr, ev_h = nullptr, ev_wm = nullptr, ev_done[5] = {};
     void* pinned = nullptr;  // window sums land here (hipHostMalloc)
     size_t pinned_bytes = 0;
     // g16_ctx_create_multi: a multi-device context owns one full context per device and no device state of its own
@@ -470,16 +471,29 @@ struct Impl {
         // every pass they ran under (8-way shard at 2^22: 1.8-2.1 ms per pass instead of 1.2) -- but run TOGETHER, one launch per
         // stage for all of them (msm_reduce_batch), after the last pass: 4x the waves per launch, one chain of latency instead of four.
         const bool short_passes = (uint64_t)pk->a_count * (uint64_t)sort_z.plan.W < 20000000ull;
+        // Timestamps: ONE event per boundary between back-to-back passes (the end of pass k is the begin of pass k + 1) instead of a
+        // start / stop / done / span-start record around every pass -- each record is a barrier packet the command processor retires
+        // before it starts the next kernel, and the four of them cost ~0.13 ms of idle GPU between two passes (kernel trace of round 3).
+        hipEvent_t pass_begin[5] = {}, pass_end[5] = {}, last_end = nullptr;
+        int n_edge = 0;
+        auto mark = [&](hipEvent_t* ev) -> int {
+            if (n_edge >= 8) return G16_ERR_INTERNAL;
+            *ev = ctx->ev_edge[n_edge++];
+            G16_HIP_TRY(hipEventRecord(*ev, s1));
+            return G16_OK;
+        };
         auto run_pass = [&](int k, auto* bases, int64_t shift, uint64_t count, const ScalarSort& ss, auto* buf) -> int {
-            G16_HIP_TRY(hipEventRecord(ctx->ev_msm_start[k], s1));
-            G16_TRY((msm_bucket_pass(bases, shift, count, ss, ctx->arena, s1, buf, &ctx->t_bucket[k])));
-            G16_HIP_TRY(hipEventRecord(ctx->ev_acc[k], s1));
+            if (last_end) pass_begin[k] = last_end;
+            else G16_TRY(mark(&pass_begin[k]));
+            G16_TRY((msm_bucket_pass(bases, shift, count, ss, ctx->arena, s1, buf, nullptr)));
+            G16_TRY(mark(&pass_end[k]));
+            last_end = pass_end[k];
             return G16_OK;
         };
         // a G1 MSM's heavy-bucket combine (buckets with many partial sums: the short top window's few hundred) goes underneath the
         // next pass on the MSM's own stream -- at most a few hundred workgroups -- so that the batched reduction starts at the bucket level
         auto heavy_early = [&](int k, const MsmBuffers<Fq>& buf, const ScalarSort& ss) -> int {
-            G16_HIP_TRY(hipStreamWaitEvent(ctx->red[k], ctx->ev_acc[k], 0));
+            G16_HIP_TRY(hipStreamWaitEvent(ctx->red[k], pass_end[k], 0));
             G16_TRY((msm_heavy_reduce<Fq>(buf, ss, ctx->red[k])));
             G16_HIP_TRY(hipEventRecord(ctx->ev_heavy[k], ctx->red[k]));
             return G16_OK;
@@ -496,7 +510,7 @@ struct Impl {
         {
             hipStream_t sr = short_passes ? ctx->red[4] : s2;
             G16_TRY(run_pass(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2));                               // prover.rs:113
-            G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_acc[4], 0));
+            G16_HIP_TRY(hipStreamWaitEvent(sr, pass_end[4], 0));
             G16_TRY((msm_reduce(buf_b2, sort_z, sr)));
             G16_TRY(copy_out(4, buf_b2, sort_z, sr));
         }
@@ -510,6 +524,7 @@ struct Impl {
             jobs[njobs++] = {1, &buf_l, &sort_z};
         } else {
             G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, pk->c_z, ctx->arena, s1, &sort_l)));
+            last_end = nullptr;   // the sort sits between the passes: this one gets its own begin mark
             G16_TRY(run_pass(1, pk->l, 0, pk->l_count, sort_l, &buf_l));
             G16_TRY(heavy_early(1, buf_l, sort_l));
             jobs[njobs++] = {1, &buf_l, &sort_l};
@@ -517,7 +532,6 @@ struct Impl {
         G16_TRY(run_pass(2, pk->a, 0, pk->a_count, sort_z, &buf_a));                                         // prover.rs:92
         G16_TRY(heavy_early(2, buf_a, sort_z));
         jobs[njobs++] = {2, &buf_a, &sort_z};
-        ctx->t_bucket[3].used = false;
         if (!skip_b_g1) {                                                                                    // prover.rs:98-108
             G16_TRY(run_pass(3, pk->b_g1, 0, pk->b_g1_count, sort_z, &buf_b1));
             G16_TRY(heavy_early(3, buf_b1, sort_z));
@@ -525,6 +539,7 @@ struct Impl {
         }
         // ---- h_acc = msm(h_query, h) (prover.rs:63-66): needs the witness map
         G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_h, 0));
+        last_end = nullptr;       // whatever stream 1 waits for here is not the h pass
         G16_TRY(run_pass(0, pk->h, 0, pk->h_count, sort_h, &buf_h));
         G16_TRY(heavy_early(0, buf_h, sort_h));
         jobs[njobs++] = {0, &buf_h, &sort_h};
@@ -585,7 +600,7 @@ struct Impl {
         memset(&tm, 0, sizeof(tm));
         auto span = [&](int k) -> double {  // bucket pass start (stream 1) -> group sums on the host (reduction stream)
             float t = 0.f;
-            return hipEventElapsedTime(&t, ctx->ev_msm_start[k], ctx->ev_done[k]) == hipSuccess ? (double)t : 0.0;
+            return (pass_begin[k] && hipEventElapsedTime(&t, pass_begin[k], ctx->ev_done[k]) == hipSuccess) ? (double)t : 0.0;
         };
         tm.witness_map_ms = ctx->t_wm.ms();
         tm.ntt_ms = ctx->t_ntt[0].ms() + ctx->t_ntt[1].ms();
@@ -595,7 +610,11 @@ struct Impl {
         tm.msm_a_ms = span(2);
         tm.msm_b_g1_ms = skip_b_g1 ? 0.0 : span(3);
         tm.msm_b_g2_ms = span(4);
-        for (int i = 0; i < 5; ++i) { tm.bucket_ms[i] = ctx->t_bucket[i].ms(); tm.bucket_pass_ms += tm.bucket_ms[i]; }
+        for (int i = 0; i < 5; ++i) {
+            float t = 0.f;
+            tm.bucket_ms[i] = (pass_begin[i] && pass_end[i] && hipEventElapsedTime(&t, pass_begin[i], pass_end[i]) == hipSuccess) ? (double)t : 0.0;
+            tm.bucket_pass_ms += tm.bucket_ms[i];
+        }
         tm.finish_ms = fold_ms;
         tm.total_ms = t_end - t_begin;
         tm.window_bits = sort_z.plan.c;
@@ -1097,6 +1116,10 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
               hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream_wm, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_dwm, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreate(&c->ev_edge[0]) == hipSuccess && hipEventCreate(&c->ev_edge[1]) == hipSuccess &&
+              hipEventCreate(&c->ev_edge[2]) == hipSuccess && hipEventCreate(&c->ev_edge[3]) == hipSuccess &&
+              hipEventCreate(&c->ev_edge[4]) == hipSuccess && hipEventCreate(&c->ev_edge[5]) == hipSuccess &&
+              hipEventCreate(&c->ev_edge[6]) == hipSuccess && hipEventCreate(&c->ev_edge[7]) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_heavy[0], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_heavy[1], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_heavy[2], hipEventDisableTiming) == hipSuccess &&
@@ -1110,8 +1133,7 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
               hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 5; ++i)
-        ok = hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming) == hipSuccess && hipEventCreate(&c->ev_done[i]) == hipSuccess &&
-             hipEventCreate(&c->ev_msm_start[i]) == hipSuccess;
+        ok = hipEventCreate(&c->ev_done[i]) == hipSuccess;
     if (!ok) {
         g16::set_last_error("stream/event creation", hipGetLastError(), __FILE__, __LINE__);
         delete c;
@@ -1177,10 +1199,11 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy(); ctx->t_ntt[0].destroy(); ctx->t_ntt[1].destroy();
     for (int i = 0; i < 5; ++i) {
         ctx->t_bucket[i].destroy();
-        (void)hipEventDestroy(ctx->ev_acc[i]); (void)hipEventDestroy(ctx->ev_done[i]); (void)hipEventDestroy(ctx->ev_msm_start[i]);
+        (void)hipEventDestroy(ctx->ev_done[i]);
     }
     (void)hipEventDestroy(ctx->ev_z); (void)hipEventDestroy(ctx->ev_h); (void)hipEventDestroy(ctx->ev_wm); (void)hipEventDestroy(ctx->ev_dwm);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_heavy[i]);
+    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev_edge[i]);
     (void)hipStreamDestroy(ctx->stream_wm);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipStreamDestroy(ctx->stream);
