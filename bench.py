@@ -404,13 +404,18 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, committed under profiles/);
         # only valid for the workload they were collected on
-        traffic, ntt_traffic = None, None
+        traffic, ntt_traffic, traffic_cal = None, None, None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             wl = pt["workload"]
             if wl["curve"] == args.curve and wl["log2_domain"] == args.log2 and wl["n_gpus"] == world:
                 traffic = pt["hbm_bytes_per_launch"]
                 ntt_traffic = pt.get("ntt_hbm_bytes_per_step")
+                cal = pt.get("calibration")
+                if cal:
+                    traffic_cal = (f"FETCH_SIZE x {cal['fetch']['factor']:.3f} ({cal['fetch']['pattern']}), WRITE_SIZE x {cal['write']['factor']:.3f} "
+                                   f"({cal['write']['pattern']}): factors of known-bytes kernels with the same access pattern run under the same "
+                                   "--pmc passes (tools/calib.hip, DESIGN.md 4.5)")
         except Exception:  # noqa: BLE001
             pass
         # the bound that actually applies: v_mad_u64_u32 issue.  Both sides of the fraction come from the library
@@ -441,6 +446,7 @@ def main():
                                 note="Fr-product bound in practice (DESIGN.md 4.2); replicated on every rank when sharded")
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload; not measured in this run)" if traffic else None,
+                        traffic_calibration=traffic_cal,
                         binding_resource="integer VALU (v_mad_u64_u32 issue), not HBM: see valu_bound",
                         valu_bound=valu,
                         kernel="bucket_accumulate30_kernel (G1 Pippenger bucket pass)", launches_per_step=len(bucket_g1) // args.steps,
