@@ -52,3 +52,21 @@ def test_streaming_kernels_have_no_scratch(kernels):
                 "bucket_count_merged_kernel", "bucket_scatter_merged_kernel", "digits_kernel", "dwm_column_kernel"):
         for name, k in pick(kernels, sub).items():
             assert k["scratch"] == 0, (name, k)
+
+
+def test_window_table_builders_have_no_per_lane_arrays(kernels):
+    """round 2's builders kept W XYZZ points in per-lane arrays: 5-17 KB of scratch per lane, 1.4 s for one G2 table.  The
+    round-3 builders (window_tables.hpp) park their rows in an explicit HBM buffer; what is left in scratch is the standard-form
+    conversion of the input point (<= 256 B), and they keep two waves per SIMD."""
+    for name, k in pick(kernels, "build_window_tables_kernel").items():
+        assert k["scratch"] <= 256, (name, k)
+        assert k["waves_per_simd"] >= 2, (name, k)
+
+
+def test_batched_g1_reduction_keeps_two_waves_per_simd(kernels):
+    """the four G1 reductions run as one throughput-bound launch per stage (msm_reduce_batch): at one wave per SIMD (the batch
+    parameter block once pushed bucket_reduce_kernel to 320 registers) they would take twice as long"""
+    for sub in ("bucket_reduce_kernel<", "window_reduce_kernel<", "heavy_reduce_kernel<"):
+        for name, k in pick(kernels, sub, "Fp30<").items():
+            assert k["waves_per_simd"] >= 2, (name, k)
+            assert k["scratch"] <= 192, (name, k)
