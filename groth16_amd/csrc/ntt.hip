@@ -3,14 +3,15 @@
 // Replaces ark-poly's Radix2EvaluationDomain::{fft,ifft}_in_place and the coset variants as
 // called from /root/reference/src/r1cs_to_qap.rs:201-207,220-221,232.
 //
-// Shape: an n-point transform is split into passes; each pass stages a tile of 2^11 elements in LDS,
-// runs up to 11 butterfly stages there and writes the tile back, so one NTT is ceil(log2 n / ~8) sweeps
+// Shape: an n-point transform is split into passes; each pass stages a tile of 2^10 elements in LDS,
+// runs up to 10 butterfly stages there and writes the tile back, so one NTT is ceil(log2 n / ~8) sweeps
 // over HBM instead of log2 n.  The last/first pass works on contiguous tiles; the others gather
-// 2^T-element runs (>= 1 KiB contiguous for T >= 5) so that every wave-level access is a full-line access.
-// Inside a pass the stages are taken three at a time: a lane pulls 8 elements out of LDS, does 12
-// butterflies in registers (radix-8 block) and puts them back -- 4 LDS round trips for 11 stages.
-// The tile is kept as structure-of-arrays of 30-bit limbs ([9][2048+pad] words, 76 KB): consecutive lanes
-// touch consecutive words, and one pad word per 32 elements breaks the stride-8 pattern of the first round.
+// 2^T-element runs (>= 128 B contiguous) so that every wave-level access is a full-line access.
+// Inside a pass the stages are taken two at a time: a lane pulls 4 elements out of LDS, does 4
+// butterflies in registers (radix-4 block) and puts them back -- 5 LDS round trips for 10 stages, <= 122 registers,
+// four workgroups per CU (round 3; round 2 used 2^11-element tiles and radix-8 blocks at two waves per SIMD).
+// The tile is kept as structure-of-arrays of 30-bit limbs ([9][1024+pad] words, 38 KB): consecutive lanes
+// touch consecutive words, and one pad word per 32 elements breaks the strided pattern of the first round.
 //
 // Arithmetic: Fr in the 30-bit lazy representation of fp30.hpp (9 limbs; a product is 162 carry-free
 // v_mad_u64_u32).  Data stays in the arkworks Montgomery form (x*R); the twiddle / scale tables are stored as
@@ -28,14 +29,30 @@
 
 namespace g16 {
 
-// G16_NTT_TILE_LOG = 12 (experiment): 2^12-element tiles, 512 lanes per workgroup, 152 KB of LDS -- one workgroup per CU instead of
-// two; a 2^22-point transform becomes two sweeps (12 + 10 stages) instead of three
+// Tile shape (round 3, profiles/r03_ab_ntt_tile_radix_occupancy.txt, one box, 2^22): 2^10-element tiles (38 KB of LDS) with radix-4
+// register blocks keep the pass kernels at <= 122 registers, so FOUR workgroups of 256 lanes share a CU (four waves per SIMD) and a
+// wave waiting at a barrier or on LDS is covered by three others: 5.48 ms for the seven transforms against 6.03 ms for the round-2
+// shape (2^11-element tiles, radix-8 blocks, 187 registers, two waves per SIMD).  Same number of sweeps (10 + 6 + 6 stages at 2^22).
+// Also measured: 2^11 tiles / 512 lanes / radix-4 / 4 waves 5.78 ms; 2^12 tiles / 1024 lanes / radix-4 (two sweeps) 6.36 ms;
+// 2^12 tiles / 512 lanes / radix-8 / 2 waves 6.06 ms.  -DG16_NTT_TILE_LOG / _THREADS / _MAX_R / _MIN_WAVES rebuild any of them.
 #ifndef G16_NTT_TILE_LOG
-#define G16_NTT_TILE_LOG 11
+#define G16_NTT_TILE_LOG 10
 #endif
 static constexpr int NTT_TILE_LOG = G16_NTT_TILE_LOG;
 static constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
+#ifdef G16_NTT_THREADS
+static constexpr int NTT_THREADS = G16_NTT_THREADS;
+#else
 static constexpr int NTT_THREADS = NTT_TILE_LOG >= 12 ? 512 : 256;
+#endif
+// stages taken together in registers: 2 = radix-4 blocks (4 elements), 3 = radix-8 blocks (8 elements, ~187 registers)
+#ifndef G16_NTT_MAX_R
+#define G16_NTT_MAX_R 2
+#endif
+static constexpr int NTT_MAX_R = G16_NTT_MAX_R;
+#ifndef G16_NTT_MIN_WAVES
+#define G16_NTT_MIN_WAVES 4
+#endif
 static constexpr int NTT_MAX_STRIDED = NTT_TILE_LOG >= 12 ? 10 : 8;   // stages per strided pass (runs of 2^(TILE_LOG - k) elements)
 static constexpr int NTT_ROW = NTT_TILE + NTT_TILE / 32;  // padded row length (words) of one limb plane
 
@@ -125,7 +142,7 @@ template <class P>
 struct NttBatch { Fp<P>* p[3]; };
 
 template <class P, bool DIT>
-__global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(NttBatch<P> batch, const Fp<P>* __restrict__ tw,
+__global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_pass_kernel(NttBatch<P> batch, const Fp<P>* __restrict__ tw,
                                                                  const Fp<P>* __restrict__ prescale, int log_n, int s_lo, int s_hi,
                                                                  int T) {
     typedef Fp30<P> F;
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(NttBatch<P> bat
     // ---- stages, three at a time in registers
     int done = 0;  // stages of this pass already applied (= how often sums may have doubled, DIF)
     while (done < K) {
-        const int R = (K - done) >= 3 ? 3 : (K - done);
+        const int R = (K - done) >= NTT_MAX_R ? NTT_MAX_R : (K - done);
         const int q0 = DIT ? done : (K - done - R);    // first (lowest) stage of this round, relative to s_lo
         if (R == 3) ntt30_round<P, DIT, 3>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx, true);
         else if (R == 2) ntt30_round<P, DIT, 2>(lds, tw, log_n, s_lo, q0, TT, E, done, gidx, true);
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_pass_kernel(NttBatch<P> bat
 // less per DIF/DIT pair (three pairs per witness map).  `prescale` is applied between the two (x lazy, < 2^K p: fine for
 // the product).
 template <class P>
-__global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(NttBatch<P> batch, const Fp<P>* __restrict__ tw_dif,
+__global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_dif_dit_kernel(NttBatch<P> batch, const Fp<P>* __restrict__ tw_dif,
                                                                     const Fp<P>* __restrict__ tw_dit, const Fp<P>* __restrict__ prescale,
                                                                     int log_n, int K) {
     typedef Fp30<P> F;
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(NttBatch<P> 
     }
     __syncthreads();
     for (int done = 0; done < K;) {
-        const int R = (K - done) >= 3 ? 3 : (K - done);
+        const int R = (K - done) >= NTT_MAX_R ? NTT_MAX_R : (K - done);
         const int q0 = K - done - R;
         // (without a pre-scale the DIT half below multiplies only the odd element of a stage-0 pair; DIF's lazy difference is
         // such an element, its lazy sum is bounded like every other DIF sum: unit0 is safe either way)
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt30_dif_dit_kernel(NttBatch<P> 
         __syncthreads();
     }
     for (int done = 0; done < K;) {
-        const int R = (K - done) >= 3 ? 3 : (K - done);
+        const int R = (K - done) >= NTT_MAX_R ? NTT_MAX_R : (K - done);
         const bool unit0 = prescale != nullptr;   // stage-0 inputs are pre-scale products (< 1.01 p); otherwise lazy DIF outputs
         if (R == 3) ntt30_round<P, true, 3>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx, unit0);
         else if (R == 2) ntt30_round<P, true, 2>(lds, tw_dit, log_n, 0, done, 0, E, done, gidx, unit0);
