@@ -317,6 +317,8 @@ def main():
         """the distributed witness map needs a power-of-two rank count <= 16 with ranks^2 | domain size; G16_BENCH_DIST_WM=0
         keeps the replicated map (A/B)"""
         lw = n_ranks.bit_length() - 1
+        if n_ranks == 1 and os.environ.get("G16_BENCH_FORCE_DWM"):   # test-only: the distributed-map path with a single rank
+            return True
         return (n_ranks > 1 and (1 << lw) == n_ranks and n_ranks <= 16 and 2 * lw <= args.log2 and
                 os.environ.get("G16_BENCH_DIST_WM", "1") != "0")
 

@@ -611,7 +611,11 @@ class DistributedWitnessMap:
         gloo in the one-GPU / CPU tests, which has no all-to-all): stage by stage with host synchronisation."""
         import torch
 
-        multi = dist is not None and self.world > 1
+        import os
+
+        # G16_DWM_FORCE_COLLECTIVE (test-only): issue the collective with one rank too, so that a one-GPU box exercises
+        # all_to_all_single over RCCL on the adopted stream exactly as the N > 1 runs do
+        multi = dist is not None and (self.world > 1 or bool(os.environ.get("G16_DWM_FORCE_COLLECTIVE")))
         if on_device and (not multi or dist.get_backend() == "nccl"):
             ext = torch.cuda.ExternalStream(int(self.lib.c.g16_ctx_wm_stream(self.ctx)), device=self.h_local.device)
             with torch.cuda.stream(ext):

@@ -114,9 +114,9 @@ def test_msm_matches_oracle(env, orc, g2, n, msm_path):
 @pytest.mark.parametrize("g2", [False, True])
 @pytest.mark.parametrize("merged", [False, True])
 def test_msm_any_segment_length(env, orc, g2, merged, seg, monkeypatch):
-    """the bucket pass walks segments of ANY length (round 3: the length is chosen so that the launch fills whole rounds of the
-    chip, e.g. 70 at 2^22 constraints, 56 for an 8-way shard): odd lengths, lengths above and below the mean bucket load, with
-    repeated scalars so that buckets span many segments (heavy-bucket path) -- result == oracle"""
+    """the bucket pass walks segments of ANY length (round 3: the kernels divide by the length instead of shifting; the plan itself
+    keeps 64 / 32 / 16 after the A/B of profiles/r03_ab_segment_length.txt): odd lengths, lengths above and below the mean bucket
+    load, with repeated scalars so that buckets span many segments (heavy-bucket path) -- result == oracle"""
     monkeypatch.setenv("G16_MSM_SEGMENT", str(seg))
     if merged:
         monkeypatch.setenv("G16_MSM_API_PRECOMP", "1")
@@ -450,3 +450,11 @@ def test_bench_rccl_single_rank():
     dd = json.loads([l for l in outd.stdout.splitlines() if l.startswith("{")][-1])
     d1 = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
     assert dd["proof_sha256"] == d1["proof_sha256"] and dd["n_gpus"] == 1
+    # the distributed witness map's RCCL path with the one rank a one-GPU box has: stages enqueued by g16_dwm_stage_async on the
+    # library's stream, all_to_all_single issued on that same stream through torch's ExternalStream, g16_prove_partial_h behind them
+    envw = dict(envd, G16_BENCH_FORCE_DWM="1", G16_DWM_FORCE_COLLECTIVE="1", MASTER_PORT=str(port + 1))
+    outw = subprocess.run(base, env=envw, capture_output=True, text=True, timeout=600)
+    assert outw.returncode == 0, outw.stderr[-3000:]
+    dw = json.loads([l for l in outw.stdout.splitlines() if l.startswith("{")][-1])
+    assert dw["proof_sha256"] == d1["proof_sha256"]
+    assert "dist_witness_map_enqueue_ms" in dw["phases_ms_per_step"], "the distributed-map path was not taken"
