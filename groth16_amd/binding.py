@@ -119,6 +119,15 @@ class Lib:
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  groth16_amd has no CPU fallback.")
         self.path = path
+        # One HIP runtime per process: torch wheels bundle their own libamdhip64, and this library links the system one.  Whichever is
+        # loaded first serves both (same soname); loaded in the order library -> torch, g16_ctx_create found no device on the GPU box
+        # (round 3: `python __graft_entry__.py smoke`, where build() loads the library before smoke() imports torch).  So when torch is
+        # installed it goes first -- every Python user of this package needs it for device buffers anyway; a C / Rust caller has no torch
+        # in the process and is not affected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.c = C.CDLL(path)
         c = self.c
         c.g16_strerror.restype = C.c_char_p
