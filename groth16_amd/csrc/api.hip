@@ -64,15 +64,15 @@ using namespace g16;
 struct g16_ctx {
     int curve;
     int device;
-    hipStream_t stream;   // bucket passes, digit/sort
-    hipStream_t stream2;  // witness digit/sort pass, then the latency-bound reductions underneath the bucket passes
+    hipStream_t stream;   // witness map, the five bucket passes back to back, the batched G1 reduction
+    hipStream_t stream2;  // witness digit/sort pass beside the witness map; the G2 reduction of a whole-key proof
     hipStream_t stream3;  // h's digit/sort pass, underneath the first bucket pass
     hipStream_t stream_wm = nullptr;   // g16_dwm_stage_async: the distributed witness map's stages (and the caller's exchanges between them)
     hipEvent_t ev_dwm = nullptr;
     hipEvent_t ev_heavy[4] = {};   // G1 MSM k's heavy-bucket combine (side stream) done
     hipEvent_t ev_edge[8] = {};    // timestamps on stream 1 at the boundaries of the bucket passes (see prove_partial)
-    hipStream_t red[5];   // one stream per MSM for its reductions: they are chains of dependent additions in a few waves
-                          // (G2: ~9 ms), so five of them side by side end sooner than one after the other
+    hipStream_t red[5];   // per MSM: the heavy-bucket combine of G1 MSM k right after its pass ([0..3]); the G2 reduction of a sharded
+                          // proof ([4]: short passes, it must not queue behind the witness sort on stream 2)
     Arena arena;
     g16_timings tm;
     EventTimer t_wm, t_prep_h, t_prep_z, t_bucket[5], t_ntt[2];
@@ -1454,7 +1454,7 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                         return G16_OK;
                     });
                 }
-                if (i == 0) dwm_ms = now_ms() - tw;   // host time to enqueue the map (the GPU runs it underneath the first MSMs' sorts)
+                if (i == 0) dwm_ms = now_ms() - tw;   // host time to enqueue the map (the GPU runs it beside the witness sort)
                 int out_rc = my;
                 if (!failed.load() && my == G16_OK) {
                     // the uploaded assignment is read by the MSM streams too: order them after the upload
