@@ -71,6 +71,16 @@ struct g16_ctx {
     hipEvent_t ev_dwm = nullptr;
     hipEvent_t ev_heavy[4] = {};   // G1 MSM k's heavy-bucket combine (side stream) done
     hipEvent_t ev_edge[8] = {};    // timestamps on stream 1 at the boundaries of the bucket passes (see prove_partial)
+    // g16_prove_partial_prepare: the witness digit/sort pass of the NEXT g16_prove_partial[_h] over (pk, z), already enqueued on
+    // stream 2 (its buffers live in the arena, which that call then must not reset)
+    struct Prepared {
+        bool valid = false;
+        const g16_pk* pk = nullptr;
+        const uint64_t* z = nullptr;
+        uint64_t n_assign = 0;
+        ScalarSort sort_z;
+    } prep;
+    void reset_arena() { arena.reset(); prep.valid = false; }
     hipStream_t red[5];   // per MSM: the heavy-bucket combine of G1 MSM k right after its pass ([0..3]); the G2 reduction of a sharded
                           // proof ([4]: short passes, it must not queue behind the witness sort on stream 2)
     Arena arena;
@@ -389,6 +399,29 @@ struct Impl {
     template <class X>
     static X load_xyzz(const uint64_t* src) { X p; memcpy(&p, src, sizeof(X)); return p; }
 
+    // the witness digit/sort pass of the next prove_partial over (pk shard, device assignment), enqueued NOW on stream 2: a caller that
+    // runs the distributed witness map first (g16_dwm_stage_async + exchanges) calls this before it, so that the sort's dozen launches
+    // are in the queues ahead of the map's forty and the two run side by side from t = 0
+    static int prove_partial_prepare(g16_ctx* ctx, const g16_pk* pkh, const g16_circuit* ckh, const uint64_t* z_dev, uint64_t n_assign) {
+        const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
+        const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
+        if (n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
+        if (pk->a_start + pk->a_count > n_assign - 1) return G16_ERR_BAD_LENGTH;
+        DrainOnError drain(ctx);
+        ctx->reset_arena();
+        const Fr* d_z = reinterpret_cast<const Fr*>(z_dev);
+        ScalarSort ss;
+        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, ctx->stream2, &ss)));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_z, ctx->stream2));
+        ctx->prep.valid = true;
+        ctx->prep.pk = pkh;
+        ctx->prep.z = z_dev;
+        ctx->prep.n_assign = n_assign;
+        ctx->prep.sort_z = ss;
+        drain.dismiss();
+        return G16_OK;
+    }
+
     // h_ext != nullptr: the witness map was computed elsewhere (the distributed map: this rank's block of h, h_ext_len
     // coefficients in the order the key's h shard was gathered in) -- it is taken as is and the map below is skipped
     static int prove_partial(g16_ctx* ctx, const g16_pk* pkh, const g16_circuit* ckh, const uint64_t* z, uint64_t n_assign, int on_device,
@@ -409,10 +442,14 @@ struct Impl {
         memset(out, 0, sizeof(*out));
         const double t_begin = now_ms();
         DrainOnError drain(ctx);
-        ctx->arena.reset();
+        // g16_prove_partial_prepare ran for exactly this (key shard, device assignment): its sort is on stream 2 already
+        const bool prepared = ctx->prep.valid && on_device && ctx->prep.pk == pkh && ctx->prep.z == z && ctx->prep.n_assign == n_assign;
+        const ScalarSort prepared_sort = ctx->prep.sort_z;
+        if (prepared) ctx->prep.valid = false;   // consumed: the arena keeps its contents for this call
+        else ctx->reset_arena();
         const Fr* d_z = nullptr;
         G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
-        G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));
+        if (!prepared) G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));
 
         // ---- witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it.  It goes FIRST,
         // alone, on stream 1 (~6 ms at 2^22): underneath the bucket passes their long-lived waves starve it (60+ ms
@@ -441,11 +478,16 @@ struct Impl {
 
         // ---- stream 2, beside the witness map: assignment = full_assignment[1..] (prover.rs:80-85), ONE digit/sort
         // pass for a, b_g1, b_g2 (and l)
-        G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
-        G16_TRY(ctx->t_prep_z.start(s2));
-        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, s2, &sort_z)));
-        G16_TRY(ctx->t_prep_z.stop(s2));
-        G16_HIP_TRY(hipEventRecord(ctx->ev_z, s2));   // (re-recorded: now also covers the witness sort)
+        if (prepared) {
+            sort_z = prepared_sort;                      // ev_z was recorded on stream 2 behind the sort by the prepare call
+            ctx->t_prep_z.used = false;
+        } else {
+            G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
+            G16_TRY(ctx->t_prep_z.start(s2));
+            G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, s2, &sort_z)));
+            G16_TRY(ctx->t_prep_z.stop(s2));
+            G16_HIP_TRY(hipEventRecord(ctx->ev_z, s2));   // (re-recorded: now also covers the witness sort)
+        }
         G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_z, 0));
         // ---- stream 3: h's digit/sort pass, underneath the first bucket pass (stream 2 stays free for the reductions)
         G16_HIP_TRY(hipStreamWaitEvent(s3, ctx->ev_wm, 0));
@@ -727,7 +769,7 @@ struct Impl {
         const DeviceCircuit<C>* ck = static_cast<const DeviceCircuit<C>*>(ckh->dc);
         if (n_assign != ck->num_variables) return G16_ERR_BAD_LENGTH;
         DrainOnError drain(ctx);
-        ctx->arena.reset();
+        ctx->reset_arena();
         const Fr* d_z = nullptr;
         G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
         Fr* d_h = nullptr;
@@ -752,7 +794,7 @@ struct Impl {
                 if (!on_device) return G16_ERR_BAD_ARG;   // a staged host copy would live in the arena the next call resets
                 d_z = reinterpret_cast<const Fr*>(z);
             } else {
-                ctx->arena.reset();
+                ctx->reset_arena();
                 G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
             }
         }
@@ -770,7 +812,7 @@ struct Impl {
         typedef XYZZ<F> X;
         hipStream_t st = ctx->stream;
         DrainOnError drain(ctx);
-        ctx->arena.reset();
+        ctx->reset_arena();
         A* d_b = nullptr;
         Fr* d_s = nullptr;
         G16_TRY(ctx->arena.alloc_n(n ? n : 1, &d_b));
@@ -819,7 +861,7 @@ struct Impl {
         Domain<C>* dom = nullptr;
         G16_TRY((domain_create<C>(log_n, st, &dom)));
         const size_t n = dom->n;
-        ctx->arena.reset();
+        ctx->reset_arena();
         Fr *d_a = nullptr, *d_o = nullptr;
         int rc = G16_OK;
         auto body = [&]() -> int {
@@ -1427,6 +1469,10 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                         zp = sl.z_dev;
                     }
                     G16_HIP_TRY(hipEventRecord(ev_up[(size_t)i], sw));
+                    // the witness sort of this device's MSMs goes into the queues ahead of the map's stages (it reads the uploaded
+                    // assignment: stream 2 waits for the upload)
+                    G16_HIP_TRY(hipStreamWaitEvent(sub->stream2, ev_up[(size_t)i], 0));
+                    G16_TRY(g16_prove_partial_prepare(sub, pk->subs[(size_t)i], circuit->subs[(size_t)i], zp, n_assign));
                     return G16_OK;
                 });
                 const double tw = now_ms();
@@ -1493,6 +1539,14 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
     int rc = g16_prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, &part);
     if (rc) return rc;
     return g16_prove_finalize(ctx, pk, &part, 1, r, s, out);
+}
+
+int g16_prove_partial_prepare(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment_dev, uint64_t n_assign) {
+    if (!ctx || !pk || !circuit || !full_assignment_dev) return G16_ERR_BAD_ARG;
+    if (pk->curve != ctx->curve || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty() || pk->ctx != ctx || circuit->ctx != ctx) return G16_ERR_BAD_ARG;
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::prove_partial_prepare(ctx, pk, circuit, full_assignment_dev, n_assign));
 }
 
 int g16_prove_partial_h(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
@@ -1640,6 +1694,7 @@ int g16_generate_parameters(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t nu
     if (!ctx->subs.empty())
         return g16_generate_parameters(ctx->subs[0], abc, num_inputs, num_constraints, num_variables, tw, g1_generator, g2_generator, out);
     G16_HIP_TRY(hipSetDevice(ctx->device));
+    ctx->prep.valid = false;   // the generator resets the arena
     try {
         if (ctx->curve == G16_BLS12_381)
             return generate_parameters_device<Bls12_381>(ctx->stream, ctx->arena, abc, num_inputs, num_constraints, num_variables, tw,

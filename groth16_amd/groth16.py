@@ -498,14 +498,28 @@ class Groth16:
                                         C.byref(part)))
         return bytes(part)
 
-    def prove_partial_h(self, pk: ProvingKey, matrices: ConstraintMatrices, full_assignment: np.ndarray, shard: Tuple[int, int],
-                        h_dev_ptr: int, h_len: int, skip_b_g1: bool = False) -> bytes:
+    def prove_partial_prepare(self, pk: ProvingKey, matrices: ConstraintMatrices, z_dev_ptr: int, n_assign: int, shard: Tuple[int, int],
+                              dist_h: bool = True):
+        """g16_prove_partial_prepare: enqueue the witness digit/sort pass of the next prove_partial[_h] over this key shard and this
+        DEVICE assignment now -- before the distributed witness map's stages -- so that the two run side by side"""
+        dpk, dck = self._pk(pk, matrices.num_instance_variables, shard, dist_h=dist_h), self._ck(matrices)
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_prove_partial_prepare(self._ctx.handle, dpk.handle, dck.handle, C.c_void_p(z_dev_ptr), n_assign))
+
+    def prove_partial_h(self, pk: ProvingKey, matrices: ConstraintMatrices, full_assignment, shard: Tuple[int, int],
+                        h_dev_ptr: int, h_len: int, skip_b_g1: bool = False, z_dev_ptr: int = 0) -> bytes:
         """g16_prove_partial_h: the shard's five partial sums with h supplied by the caller (device memory: this rank's block of
-        the distributed witness map); the key shard is the one gathered in that block order (dist_h)"""
+        the distributed witness map); the key shard is the one gathered in that block order (dist_h).  z_dev_ptr != 0: the
+        assignment is taken from device memory (`full_assignment` then only gives the length)"""
         dpk, dck = self._pk(pk, matrices.num_instance_variables, shard, dist_h=True), self._ck(matrices)
-        z = _c(full_assignment)
         part = PartialC()
         lb = self._ctx.lib
+        if z_dev_ptr:
+            n_assign = matrices.num_instance_variables + matrices.num_witness_variables
+            lb.check(lb.c.g16_prove_partial_h(self._ctx.handle, dpk.handle, dck.handle, C.c_void_p(z_dev_ptr), n_assign, 1, C.c_void_p(h_dev_ptr),
+                                              h_len, int(skip_b_g1), C.byref(part)))
+            return bytes(part)
+        z = _c(full_assignment)
         lb.check(lb.c.g16_prove_partial_h(self._ctx.handle, dpk.handle, dck.handle, z.ctypes.data, z.shape[0], 0, C.c_void_p(h_dev_ptr), h_len,
                                           int(skip_b_g1), C.byref(part)))
         return bytes(part)

@@ -193,6 +193,12 @@ int g16_dwm_stage(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assi
 void* g16_ctx_wm_stream(g16_ctx* ctx);
 int g16_dwm_stage_async(g16_ctx* ctx, g16_dwm* d, int stage, const uint64_t* full_assignment_dev, uint64_t n_assign,
                         uint64_t* const work[3], uint64_t* const recv[3], uint64_t* h_local);
+/* Optional, before the stages above: enqueue NOW the witness digit/sort pass (shared by the MSMs of prover.rs:74,92,105,113) that the
+ * next g16_prove_partial / g16_prove_partial_h over the same (pk shard, device assignment) would otherwise enqueue after the map's
+ * forty launches -- so that sort and map run side by side from the start.  The next such call consumes it; any other call on the
+ * context drops it (the sort's buffers live in the per-call arena). */
+int g16_prove_partial_prepare(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment_dev,
+                              uint64_t n_assign);
 /* g16_prove_partial with h supplied by the caller (device memory, h_len Fr; the key's h shard indexes it from h.start) */
 int g16_prove_partial_h(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
                         int assignment_on_device, const uint64_t* h_dev, uint64_t h_len, int skip_b_g1, g16_partial* out);

@@ -134,9 +134,14 @@ def test_async_stages_one_rank_then_proof(g, orc, curve, k):
         d = DistributedWitnessMap(prover._ctx.lib, prover._ctx.handle, dck.handle, 0, 1, "cuda:0")
         z_dev = torch.from_numpy(np.ascontiguousarray(ck.z).view(np.int64)).to("cuda:0")
         torch.cuda.synchronize()
-        for _ in range(3):   # repeated: stale events / buffers of an earlier round must not satisfy a later one
+        for it in range(4):   # repeated: stale events / buffers of an earlier round must not satisfy a later one
+            # rounds 1 and 3: the witness sort enqueued ahead of the map (g16_prove_partial_prepare) and consumed by the partial
+            # call on the same device assignment; round 2: prepared, but the partial call passes the HOST assignment -- the
+            # prepared sort must be dropped, not used; round 0: no prepare
+            if it:
+                prover.prove_partial_prepare(gp, gm, z_dev.data_ptr(), z_dev.shape[0], (0, 1))
             h = d.run(z_dev.data_ptr(), z_dev.shape[0], True, None)
-            part = prover.prove_partial_h(gp, gm, ck.z, (0, 1), h.data_ptr(), d.M)
+            part = prover.prove_partial_h(gp, gm, ck.z, (0, 1), h.data_ptr(), d.M, z_dev_ptr=z_dev.data_ptr() if it in (1, 3) else 0)
             proof = prover.prove_finalize(gp, ck.num_inputs, [part], r, s, (0, 1), dist_h=True)
             assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
         torch.cuda.synchronize()
