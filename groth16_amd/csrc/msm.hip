@@ -688,6 +688,14 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
         plan->B = 1u << (c - 1);
         plan->groups = W;
     }
+    // buckets per lane of the bucket reduction: 16 for the 2^19-bucket sets of whole keys (the window level's tree sums halve;
+    // the bucket level keeps >= 2 waves per SIMD when four MSMs are reduced together), 8 otherwise (a 2^18-bucket shard would
+    // drop to one wave per SIMD); G16_MSM_REDUCE_G forces 4 / 8 / 16 / 32 (A/B)
+    plan->G = (plan->merged && plan->buckets() >= (1u << 19)) ? 16u : REDUCE_G;
+    if (const char* e = getenv("G16_MSM_REDUCE_G")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16 || v == 32) plan->G = (uint32_t)v;
+    }
     const uint64_t all_entries = n * (uint64_t)W;
     // batched-affine levels: they pay when buckets are long (each level halves a bucket's entries at ~0.6 of the XYZZ cost
     // per addition, but a lane needs >= ~16 pairs to amortise its inversion and the chip >= ~2 k waves to stay busy)
@@ -857,7 +865,7 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
     typedef AccRaw<typename Lazy30<F>::type::Raw> Raw;
     const MsmPlan& plan = ss.plan;
     const uint32_t M = plan.buckets();
-    const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
+    const uint32_t G = plan.chunk_buckets();
     const uint32_t cpw = plan.B / G;
     const int R = plan.affine_levels;
     Raw *partials = nullptr, *chunk_out = nullptr;
@@ -978,7 +986,7 @@ int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* 
     const MsmPlan& plan = sorts[0]->plan;
     for (int i = 1; i < n; ++i)
         if (sorts[i]->plan.B != plan.B || sorts[i]->plan.groups != plan.groups) return G16_ERR_INTERNAL;   // one launch = one plan
-    const uint32_t G = plan.B >= REDUCE_G ? REDUCE_G : plan.B;
+    const uint32_t G = plan.chunk_buckets();
     const uint32_t cpw = plan.B / G;
     size_t lds_heavy, lds_win;
     G16_TRY(reduce_setup<F>(&lds_heavy, &lds_win));

@@ -115,6 +115,23 @@ def test_host_msm_model(lb, orc, cp, c_win):
 
 
 @pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("G", [4, 16, 32])
+@pytest.mark.parametrize("c_win", [7, -12, -17])
+def test_host_msm_model_buckets_per_lane(lb, orc, cp, c_win, G, monkeypatch):
+    """the bucket reduction's chunk size G (buckets per lane; 8 by default, 16 for 2^19-bucket sets since round 3) enters the
+    recombination P_0 + G sum_k 2^k P_(2+k) and the number of bit planes: the CPU model of the scheme against the oracle for
+    other chunk sizes, per-window and merged (two and several classes)"""
+    monkeypatch.setenv("G16_MSM_REDUCE_G", str(G))
+    n = 120
+    bases = orc.synth_bases(cp.name, False, 6, n)
+    sc = orc.rand_fr(cp.name, 300 + G, n)
+    sc[5:40] = sc[5]
+    out = np.zeros(bases.shape[1], dtype=np.uint64)
+    assert lb.c.g16_host_msm_model(CURVE_ID[cp.name], 0, ptr64(bases), ptr64(sc), n, c_win, ptr64(out)) == 0
+    assert (out == orc.msm(cp.name, False, bases, sc)).all()
+
+
+@pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
 def test_host_selftest_fp30(lb, cp):
     """reduced-radix lazy arithmetic of the G1 bucket kernel (fp30.hpp) vs the standard field / group code"""
     for seed in (1, 2, 3):

@@ -130,6 +130,23 @@ def test_msm_any_segment_length(env, orc, g2, merged, seg, monkeypatch):
     assert (got == orc.msm(curve, g2, bases, sc)).all()
 
 
+@pytest.mark.parametrize("G", [4, 16, 32])
+@pytest.mark.parametrize("g2", [False, True])
+@pytest.mark.parametrize("merged", [False, True])
+def test_msm_buckets_per_lane_of_the_reduction(env, orc, g2, merged, G, monkeypatch):
+    """G16_MSM_REDUCE_G: the chunk size of the bucket reduction (8 by default, 16 for the 2^19-bucket sets of whole keys) changes
+    the chunk count, the number of bit planes and the host's recombination -- result == oracle for every size"""
+    monkeypatch.setenv("G16_MSM_REDUCE_G", str(G))
+    if merged:
+        monkeypatch.setenv("G16_MSM_API_PRECOMP", "1")
+    curve, prover = env
+    n = 6000
+    bases = orc.synth_bases(curve, g2, 8, n)
+    sc = orc.rand_fr(curve, 60 + G, n)
+    sc[200:900] = sc[200]
+    assert (prover.msm(bases, sc, g2) == orc.msm(curve, g2, bases, sc)).all()
+
+
 @pytest.mark.parametrize("g2", [False, True])
 def test_msm_adversarial_inputs(env, orc, g2, msm_path):
     """zero scalars, r-1, all-equal scalars (benches/bench.rs:52-54 shape), identity bases, repeated
