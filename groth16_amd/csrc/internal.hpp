@@ -178,8 +178,7 @@ struct MsmPlan {
     // the chunk offsets b_lo = G * ch are applied WITHOUT a scalar multiplication in the dependent chain: the window level
     // sums the chunk sums once per bit of ch (masked tree sums, all in parallel) and the host recombines
     //   sum_b (b + 1) S_b = P_0 + G * sum_k 2^k P_(2+k),   sum_b S_b = P_1.
-    uint32_t G = 8;     // buckets per lane of the bucket reduction (power of two): 8, or 16 for bucket sets of 2^19 and more, where the
-                        // window level -- one tree sum per (class, bit plane) over B / G chunk sums -- is the longer half of the reduction
+    uint32_t G = 8;     // buckets per lane of the bucket reduction (power of two; 8 -- other sizes measured no faster, see make_msm_plan)
     uint32_t chunk_buckets() const { return B >= G ? G : B; }
     uint32_t chunks() const { return B / chunk_buckets(); }
     int chunk_bits() const { int k = 0; while ((1u << k) < chunks()) ++k; return k; }

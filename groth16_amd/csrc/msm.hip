@@ -688,10 +688,10 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
         plan->B = 1u << (c - 1);
         plan->groups = W;
     }
-    // buckets per lane of the bucket reduction: 16 for the 2^19-bucket sets of whole keys (the window level's tree sums halve;
-    // the bucket level keeps >= 2 waves per SIMD when four MSMs are reduced together), 8 otherwise (a 2^18-bucket shard would
-    // drop to one wave per SIMD); G16_MSM_REDUCE_G forces 4 / 8 / 16 / 32 (A/B)
-    plan->G = (plan->merged && plan->buckets() >= (1u << 19)) ? 16u : REDUCE_G;
+    // buckets per lane of the bucket reduction: 8.  16 halves the window level's tree sums but doubles the bucket level's chain;
+    // measured at 2^22 on one box (round 3, tools/ab_reduce_g.sh): 8: 77.50 / 78.11 ms, 16: 78.27 / 77.81 ms, 32: 80.56 ms -- no
+    // gain, so 8 stays.  G16_MSM_REDUCE_G forces 4 / 8 / 16 / 32 (tests, A/B).
+    plan->G = REDUCE_G;
     if (const char* e = getenv("G16_MSM_REDUCE_G")) {
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16 || v == 32) plan->G = (uint32_t)v;
