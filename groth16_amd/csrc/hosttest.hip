@@ -5,6 +5,7 @@
 #include "batch_affine.hpp"
 #include "window_tables.hpp"
 #include "fixed_base.hpp"
+#include <cstdlib>
 #include <vector>
 
 using namespace g16;
@@ -27,6 +28,55 @@ struct Fp2e30 {
 };
 template <class P>
 Fp2e30<P> batch_inverse(const Fp2e30<P>& a) { return {pair_inverse<P>(false, a.c0, a.c1), pair_inverse<P>(true, a.c1, a.c0)}; }
+
+// Bound-tracking stand-in for the lazy field: a "value" is only an upper bound b (the value is < b p, per base-field component),
+// every operation propagates the bound by the rule its real counterpart obeys and CHECKS the real counterpart's precondition:
+//   sub<K>(o)   needs o < K p (the redundant K p never borrows)                            -> a + K
+//   mul / sqr   need both operands below R' (they must fit NL limbs); with T = the sum of the sweeps' products the Montgomery
+//               output (T + m p) / R' is below p (1 + T / (R' p))                        -> 1 + T / (R' p)
+//               (fp30.hpp's "A B p / R' <= 0.5" is the sufficient condition for outputs < 1.5 p; the lane-pair squaring of the
+//               9.5 p difference P exceeds it -- 484 of R'/p = 630 -- and yields < 1.77 p, which every later K still covers:
+//               exactly what this propagation verifies)
+//   exact zero tests need < 16 p; canonical_lt2p needs < 2 p
+// PAIR: the lane-pair Fq2 -- a product is a0 b0 + a1 (16p - b1) (resp. a0 b1 + a1 b0): T <= A B + 16 A; a squaring multiplies
+// (a0 + a1) by (a0 - a1 + 16p).  Plugged into Acc30 and jac30_double, the REAL formula code runs on bounds, so the invariants
+// the kernels rely on ("x < 7.5p, y < 3.5p, ...") are derived and every K of every subtraction is checked, not argued.
+struct BoundCtx {
+    double ratio = 0;      // R' / p
+    bool pair = false;
+    const char* fail = nullptr;
+    double worst_mul = 0, worst_operand = 0;
+};
+template <int TAG>
+struct BoundF {
+    typedef BoundF Std;
+    typedef BoundF Raw;
+    static BoundCtx& ctx() { static BoundCtx c; return c; }
+    double b;
+    static void check(bool ok, const char* what) { if (!ok && !ctx().fail) ctx().fail = what; }
+    static BoundF zero() { return {0.0}; }
+    static BoundF one() { return {1.0}; }
+    BoundF add(const BoundF& o) const { return {b + o.b}; }
+    BoundF dbl() const { return {2.0 * b}; }
+    template <int K> BoundF sub(const BoundF& o) const { check(o.b <= K - 1e-3, "sub<K>: subtrahend not below K p"); return {b + K}; }
+    BoundF neg2() const { check(b <= 2.0 - 1e-3 || b == 1.0, "neg2: operand not below 2p"); return {2.0}; }
+    static BoundF product(double A, double B, double T) {
+        BoundCtx& c = ctx();
+        check(A < c.ratio && B < c.ratio, "product operand does not fit NL limbs");
+        if (T / c.ratio > c.worst_mul) c.worst_mul = T / c.ratio;
+        if (A > c.worst_operand) c.worst_operand = A;
+        if (B > c.worst_operand) c.worst_operand = B;
+        return {1.0 + T / c.ratio};
+    }
+    BoundF mul(const BoundF& o) const { return ctx().pair ? product(b, o.b > 16.0 ? o.b : 16.0, b * o.b + b * 16.0) : product(b, o.b, b * o.b); }
+    BoundF sqr() const { return ctx().pair ? product(2.0 * b, b + 16.0, 2.0 * b * (b + 16.0)) : product(b, b, b * b); }
+    static BoundF mul_sub(const BoundF& a, const BoundF& bb, const BoundF& c, const BoundF& d) { return a.mul(bb).template sub<2>(c.mul(d)); }
+    BoundF settle() const { return *this; }
+    bool maybe_zero() const { check(b < 16.0, "zero test on a value not below 16p"); return false; }
+    bool is_zero_exact() const { check(b < 16.0, "zero test on a value not below 16p"); return false; }
+    static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
+    static constexpr int LANES_PER_TASK = 1;
+};
 }  // namespace g16
 
 namespace {
@@ -367,6 +417,73 @@ struct SelfTest {
         return 0;
     }
 
+    // ---------------------------------------------------------------------------------------
+    // lazy-arithmetic invariants by bound propagation (BoundF above): the mixed addition / full addition / doubling of the bucket and
+    // reduction kernels iterated to a fixed point from the worst admissible inputs, and the Jacobian doubling of the table builder;
+    // G1 rules and lane-pair rules, this curve's R' / p.  Returns 0 or a code; *report gets the failing precondition.
+    template <int TAG>
+    static int bounds_case(bool pair, const char** report) {
+        typedef BoundF<TAG> B;
+        BoundCtx& c = B::ctx();
+        c = BoundCtx();
+        double ratio = 1.0;   // R' / p = 2^(30 NL) / p from the limbs of p
+        {
+            double pv = 0.0;
+            for (int i = F30::NL - 1; i >= 0; --i) pv = pv * 1073741824.0 + (double)Fq::Params::p30(i);
+            double rp = 1.0;
+            for (int i = 0; i < F30::NL; ++i) rp *= 1073741824.0;
+            ratio = rp / pv;
+        }
+        c.ratio = ratio;
+        c.pair = pair;
+        typedef Acc30<B> A;
+        // mixed additions: px canonical (< p), py canonical or 2p - y (< 2p)
+        A acc = A::identity();
+        double mx[4] = {0, 0, 0, 0};
+        for (int it = 0; it < 200; ++it) {
+            acc.add_affine(B{1.0}, B{2.0});
+            const double v[4] = {acc.x.b, acc.y.b, acc.zz.b, acc.zzz.b};
+            for (int k = 0; k < 4; ++k) if (v[k] > mx[k]) mx[k] = v[k];
+        }
+        if (c.fail) { *report = c.fail; return 1; }
+        // the invariants fp30.hpp documents for the accumulator
+        if (!(mx[0] < 7.5 && mx[1] < 3.5 && mx[2] < 1.8 && mx[3] < 1.8)) { *report = "accumulator bounds above the documented ones"; return 2; }
+        // full additions, doublings, mixed doubling on accumulators at those bounds (reduction kernels, heavy combine, P + P branch)
+        A a1; a1.x = B{mx[0]}; a1.y = B{mx[1]}; a1.zz = B{mx[2]}; a1.zzz = B{mx[3]}; a1.inf = false;
+        A a2 = a1;
+        for (int it = 0; it < 50; ++it) { a1.add(a2); a2 = a1; a2.dbl(); }
+        A a3 = A::identity();
+        a3.set_double(B{1.0}, B{2.0});
+        if (c.fail) { *report = c.fail; return 3; }
+        // window-table builder: Jacobian doublings from an affine point
+        B X{1.0}, Y{1.0}, Z{1.0};
+        double jm[3] = {0, 0, 0};
+        for (int it = 0; it < 400; ++it) {
+            jac30_double(X, Y, Z);
+            if (X.b > jm[0]) jm[0] = X.b;
+            if (Y.b > jm[1]) jm[1] = Y.b;
+            if (Z.b > jm[2]) jm[2] = Z.b;
+        }
+        if (c.fail) { *report = c.fail; return 4; }
+        if (!(jm[0] < 5.8 && jm[1] < 5.5 && jm[2] < 3.0)) { *report = "Jacobian doubling bounds above the documented ones"; return 5; }
+        // rows leave the builder through canonical_lt2p of a product whose operands are X (resp. Y) and an inverse power (< 2p)
+        if (getenv("G16_SELFTEST_VERBOSE"))
+            fprintf(stderr, "g16 self-test bounds (%s, R'/p = %.0f): accumulator x < %.2fp y < %.2fp zz < %.2fp zzz < %.2fp; Jacobian X < %.2fp Y < %.2fp "
+                            "Z < %.2fp; largest product T / (R' p) = %.3f, largest operand %.1fp\n",
+                    pair ? "lane pair" : "one lane", ratio, mx[0], mx[1], mx[2], mx[3], jm[0], jm[1], jm[2], c.worst_mul, c.worst_operand);
+        const B ax = X.mul(B{2.0}), ay = Y.mul(B{2.0});
+        if (c.fail || !(ax.b < 2.0 && ay.b < 2.0)) { *report = c.fail ? c.fail : "table row not below 2p before canonical_lt2p"; return 6; }
+        return 0;
+    }
+    static int selftest_bounds() {
+        const char* why = nullptr;
+        int rc = bounds_case<0>(false, &why);
+        if (rc) { fprintf(stderr, "g16 self-test: G1 lazy bounds: %s\n", why); return 800 + rc; }
+        rc = bounds_case<1>(true, &why);
+        if (rc) { fprintf(stderr, "g16 self-test: lane-pair lazy bounds: %s\n", why); return 810 + rc; }
+        return 0;
+    }
+
     static int selftest30(uint64_t seed, int iters) {
         uint64_t st = seed;
         {
@@ -387,6 +504,10 @@ struct SelfTest {
         }
         {
             const int rc = selftest_window_table(seed);
+            if (rc) return rc;
+        }
+        {
+            const int rc = selftest_bounds();
             if (rc) return rc;
         }
         for (int it = 0; it < iters; ++it) {
