@@ -112,3 +112,129 @@ def test_bn254_generator_doubling_eip196_gpu_msm():
         for scalars in ([1, 1], [2, 0], [cp.r - 1, 3]):
             out = prover.msm(gen, ints_to_mont(scalars, cp.r, 4))
             assert arr_to_g1(out[None, :], cp)[0] == EIP196_2G
+
+
+# ---- round 3: more published constants -------------------------------------------------------------------------------------
+# Ethereum consensus-layer (eth2) BLS public keys of the secret keys 2 and 3 = compressed 2 G1, 3 G1 in the zcash / IETF encoding
+# (secret key 1 gives the generator's encoding above).  They pin doubling, addition and the y-sort flag of BLS12-381 G1.
+ETH2_PUBKEY_SK2 = "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e"
+ETH2_PUBKEY_SK3 = "89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224"
+# zkcrypto/bls12_381 scalar.rs: ROOT_OF_UNITY (= GENERATOR^t with GENERATOR = 7, a primitive 2^32-th root of unity) and R = 2^256 mod r,
+# both as four little-endian u64 limbs IN MONTGOMERY FORM -- the in-memory form of ark_ff::Fp and of every Fr that crosses this C ABI.
+ZKCRYPTO_ROOT_OF_UNITY = [0xB9B58D8C5F0E466A, 0x5B1B4C801819D7EC, 0x0AF53AE352A31E64, 0x5BF3ADDA19E9B27B]
+ZKCRYPTO_R = [0x00000001FFFFFFFE, 0x5884B7FA00034802, 0x998C4FEFECBC4FF5, 0x1824B159ACC5056F]
+# EIP-196 (alt_bn128) test vectors: 3 * (1, 2)
+EIP196_3G = (3353031288059533942658390886683067124040920775575537747144343083137631628272,
+             19321533766552368860946552437480515441416830039777911637913418824951667761761)
+
+
+def test_bls12_381_eth2_pubkeys_of_sk_2_and_3():
+    """model, oracle, the product's host group code and the product's serialiser against the published encodings"""
+    import groth16_amd as g
+    import groth16_amd.serialize as ser
+
+    cp = pm.BLS12_381
+    G1, _ = pm.groups(cp)
+    gen = g1_to_arr([cp.g1], cp)[0]
+    lb, orc = g.lib(), oracle()
+    for k, want_hex in ((2, ETH2_PUBKEY_SK2), (3, ETH2_PUBKEY_SK3)):
+        assert pm.compress_g1_bls(G1.mul(cp.g1, k)).hex() == want_hex
+        kb = np.array([k, 0, 0, 0], dtype=np.uint64)
+        out = np.zeros_like(gen)
+        assert lb.c.g16_host_group_op(CURVE_ID[cp.name], 0, 1, ptr64(gen), ptr64(kb), ptr64(out)) == 0
+        assert ser.serialize_points(cp.name, out[None, :], False, True).hex() == want_hex
+        assert ser.serialize_points(cp.name, orc.group_op(cp.name, False, 1, gen, kb)[None, :], False, True).hex() == want_hex
+    # 2 G + G through the affine addition of the host code
+    two, out = np.zeros_like(gen), np.zeros_like(gen)
+    assert lb.c.g16_host_group_op(CURVE_ID[cp.name], 0, 0, ptr64(gen), ptr64(gen), ptr64(two)) == 0
+    assert lb.c.g16_host_group_op(CURVE_ID[cp.name], 0, 0, ptr64(two), ptr64(gen), ptr64(out)) == 0
+    assert ser.serialize_points(cp.name, out[None, :], False, True).hex() == ETH2_PUBKEY_SK3
+
+
+def test_bls12_381_scalar_field_montgomery_constants_zkcrypto():
+    """the 2^32-th root of unity the NTT domains are built from and the Montgomery radix, as another library publishes them limb
+    for limb: 7^((r - 1) / 2^32) * 2^256 mod r and 2^256 mod r -- through the model and through the product's own Fr code
+    (from_canonical = the conversion every caller-supplied scalar has undergone on the Rust side)"""
+    import groth16_amd as g
+
+    cp = pm.BLS12_381
+    root = pow(7, (cp.r - 1) >> 32, cp.r)
+    assert pow(root, 1 << 32, cp.r) == 1 and pow(root, 1 << 31, cp.r) != 1
+    limbs = lambda v: [(v >> (64 * i)) & (2**64 - 1) for i in range(4)]  # noqa: E731
+    assert limbs(root * (1 << 256) % cp.r) == ZKCRYPTO_ROOT_OF_UNITY
+    assert limbs((1 << 256) % cp.r) == ZKCRYPTO_R
+    lb = g.lib()
+    out = np.zeros(4, dtype=np.uint64)
+    for canonical, want in ((root, ZKCRYPTO_ROOT_OF_UNITY), (1, ZKCRYPTO_R)):
+        a = np.array(limbs(canonical), dtype=np.uint64)
+        assert lb.c.g16_host_field_op(CURVE_ID[cp.name], 0, 5, ptr64(a), None, ptr64(out)) == 0      # from_canonical
+        assert [int(x) for x in out] == want
+        back = np.zeros(4, dtype=np.uint64)
+        assert lb.c.g16_host_field_op(CURVE_ID[cp.name], 0, 4, ptr64(out.copy()), None, ptr64(back)) == 0   # to_canonical
+        assert [int(x) for x in back] == limbs(canonical)
+
+
+def test_bn254_generator_tripling_eip196():
+    import groth16_amd as g
+
+    cp = pm.BN254
+    G1, _ = pm.groups(cp)
+    assert G1.mul(cp.g1, 3) == EIP196_3G and G1.add(EIP196_2G, cp.g1) == EIP196_3G
+    gen, want = g1_to_arr([cp.g1], cp)[0], g1_to_arr([EIP196_3G], cp)[0]
+    out = np.zeros_like(gen)
+    three = np.array([3, 0, 0, 0], dtype=np.uint64)
+    assert g.lib().c.g16_host_group_op(CURVE_ID[cp.name], 0, 1, ptr64(gen), ptr64(three), ptr64(out)) == 0 and (out == want).all()
+    assert (oracle().group_op(cp.name, False, 1, gen, three) == want).all()
+
+
+@pytest.mark.gpu
+def test_published_multiples_through_gpu_msm():
+    """the eth2 public keys (BLS12-381) and EIP-196's 3 G (BN254) as GPU MSM results, per-window and merged-window paths"""
+    import os
+
+    import groth16_amd as g
+    import groth16_amd.serialize as ser
+    from helpers import ints_to_mont
+
+    for precomp in ("0", "1"):
+        os.environ["G16_MSM_API_PRECOMP"] = precomp
+        try:
+            cp = pm.BLS12_381
+            gen = g1_to_arr([cp.g1, cp.g1, cp.g1], cp)
+            with g.Groth16(cp.name, 0) as prover:
+                for scalars, want_hex in (([1, 1, 0], ETH2_PUBKEY_SK2), ([2, 0, 0], ETH2_PUBKEY_SK2), ([1, 1, 1], ETH2_PUBKEY_SK3), ([cp.r - 1, 4, 0], ETH2_PUBKEY_SK3)):
+                    out = prover.msm(gen, ints_to_mont(scalars, cp.r, 4))
+                    assert ser.serialize_points(cp.name, out[None, :], False, True).hex() == want_hex
+            cp = pm.BN254
+            gen = g1_to_arr([cp.g1, cp.g1, cp.g1], cp)
+            with g.Groth16(cp.name, 0) as prover:
+                for scalars in ([1, 1, 1], [3, 0, 0], [cp.r - 2, 2, 3]):
+                    assert arr_to_g1(prover.msm(gen, ints_to_mont(scalars, cp.r, 4))[None, :], cp)[0] == EIP196_3G
+        finally:
+            os.environ.pop("G16_MSM_API_PRECOMP", None)
+
+
+def test_bn254_scalar_field_two_adic_root_published():
+    """the primitive 2^28-th root of unity of the BN254 scalar field that libff / snarkjs / gnark publish for alt_bn128, which is
+    5^((r - 1) / 2^28) -- arkworks' TWO_ADIC_ROOT_OF_UNITY for GENERATOR = 5; through the model and the product's Fr code"""
+    import groth16_amd as g
+
+    cp = pm.BN254
+    published = 19103219067921713944291392827692070036145651957329286315305642004821462161904
+    assert pow(5, (cp.r - 1) >> 28, cp.r) == published
+    assert pow(published, 1 << 28, cp.r) == 1 and pow(published, 1 << 27, cp.r) == cp.r - 1
+    # the product's Fr: from_canonical then 28 squarings (g16_host_field_op mul) give one; 27 give -1
+    lb = g.lib()
+    limbs = lambda v: np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)  # noqa: E731
+    x = np.zeros(4, dtype=np.uint64)
+    assert lb.c.g16_host_field_op(CURVE_ID[cp.name], 0, 5, ptr64(limbs(published)), None, ptr64(x)) == 0
+    one, minus_one = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    assert lb.c.g16_host_field_op(CURVE_ID[cp.name], 0, 5, ptr64(limbs(1)), None, ptr64(one)) == 0
+    assert lb.c.g16_host_field_op(CURVE_ID[cp.name], 0, 5, ptr64(limbs(cp.r - 1)), None, ptr64(minus_one)) == 0
+    for i in range(28):
+        if i == 27:
+            assert (x == minus_one).all()
+        y = np.zeros(4, dtype=np.uint64)
+        assert lb.c.g16_host_field_op(CURVE_ID[cp.name], 0, 2, ptr64(x.copy()), ptr64(x.copy()), ptr64(y)) == 0
+        x = y
+    assert (x == one).all()
