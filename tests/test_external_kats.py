@@ -238,3 +238,36 @@ def test_bn254_scalar_field_two_adic_root_published():
         assert lb.c.g16_host_field_op(CURVE_ID[cp.name], 0, 2, ptr64(x.copy()), ptr64(x.copy()), ptr64(y)) == 0
         x = y
     assert (x == one).all()
+
+
+# Montgomery "one" (R mod p) of the four fields as other libraries publish it limb for limb (zkcrypto/bls12_381 fp.rs `R`, `R2`;
+# bellman / ff-derived BN256 Fq and Fr `R`): pins the little-endian u64 Montgomery limb form in which coordinates and scalars cross
+# this C ABI (= ark_ff::Fp's in-memory form) for BOTH curves, independently of the repository's own models.
+PUBLISHED_R = {
+    ("bls12_381", 1): [0x760900000002FFFD, 0xEBF4000BC40C0002, 0x5F48985753C758BA, 0x77CE585370525745, 0x5C071A97A256EC6D, 0x15F65EC3FA80E493],
+    ("bls12_381", 0): ZKCRYPTO_R,
+    ("bn254", 1): [0xD35D438DC58F0D9D, 0x0A78EB28F5C70B3D, 0x666EA36F7879462C, 0x0E0A77C19A07DF2F],
+    ("bn254", 0): [0xAC96341C4FFFFFFB, 0x36FC76959F60CD29, 0x666EA36F7879462E, 0x0E0A77C19A07DF2F],
+}
+ZKCRYPTO_FQ_R2 = [0xF4DF1F341C341746, 0x0A76E6A609D104F1, 0x8DE5476C4C95B6D5, 0x67EB88A9939D83C0, 0x9A793E85B519952D, 0x11988FE592CAE3AA]
+
+
+@pytest.mark.parametrize("curve,which", sorted(PUBLISHED_R))
+def test_montgomery_one_matches_published_limbs(curve, which):
+    import groth16_amd as g
+
+    cp = {"bls12_381": pm.BLS12_381, "bn254": pm.BN254}[curve]
+    p = cp.q if which else cp.r
+    want = PUBLISHED_R[(curve, which)]
+    nl = len(want)
+    assert [(((1 << (64 * nl)) % p) >> (64 * i)) & (2**64 - 1) for i in range(nl)] == want
+    one = np.zeros(nl, dtype=np.uint64)
+    one[0] = 1
+    out = np.zeros(nl, dtype=np.uint64)
+    lb = g.lib()
+    assert lb.c.g16_host_field_op(CURVE_ID[curve], which, 5, ptr64(one), None, ptr64(out)) == 0      # from_canonical(1)
+    assert [int(x) for x in out] == want
+    if (curve, which) == ("bls12_381", 1):   # and R^2: from_canonical(R) (what a "to Montgomery" conversion multiplies by)
+        r_can = np.array(want, dtype=np.uint64)
+        assert lb.c.g16_host_field_op(CURVE_ID[curve], which, 5, ptr64(r_can), None, ptr64(out)) == 0
+        assert [int(x) for x in out] == ZKCRYPTO_FQ_R2
