@@ -50,7 +50,8 @@
 namespace g16 {
 
 static constexpr int SORT_THREADS = 1024;
-static constexpr int ACC_THREADS = 128;
+static constexpr int ACC_THREADS = 64;   // one wave per workgroup: finer re-dispatch granularity.  Same box, full proof at 2^22 (round 3): 64 lanes
+                                         // 79.56 ms (G2 pass 25.87), 128 lanes 80.38 / 80.17 (26.53 / 26.44), 256 lanes 80.81 (26.76); G1 passes equal
 static constexpr int RED_THREADS = 64;
 static constexpr int WIN_THREADS = 256;  // lanes of the per-window reduction
 #ifndef G16_REDUCE_G
