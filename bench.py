@@ -195,6 +195,23 @@ class DeviceProver:
         self.lib.check(self.lib.c.g16_get_timings(self.ctx, C.byref(t)))
         return t.as_dict()
 
+    def close(self):
+        """give the HBM back (window tables, circuit, arena) -- the configs[4] leg loads a 2^24 shard after the 2^22 one"""
+        if self.dwm is not None:
+            self.dwm.close()
+            self.dwm = None
+        if self.pk:
+            self.lib.c.g16_pk_free(self.pk)
+            self.pk = None
+        if self.ck:
+            self.lib.c.g16_circuit_free(self.ck)
+            self.ck = None
+        if self.ctx:
+            self.lib.c.g16_ctx_destroy(self.ctx)
+            self.ctx = None
+        self.bufs = self._full = self.z_dev = None
+        torch.cuda.empty_cache()
+
 
 def prove_step(p, dist, device):
     part = p.partial(dist=dist)
@@ -205,6 +222,16 @@ def prove_step(p, dist, device):
     dist.all_gather(outs, t)  # RCCL over xGMI: ~1.2 KB per rank, one collective per proof
     parts = [PartialC.from_buffer_copy(o.cpu().numpy().tobytes()) for o in outs]
     return p.finalize(parts)
+
+
+def cpu_quota():
+    """CPUs this container may actually burn (cgroup cpu.max), or None when unlimited -- `cores` in the cpu_baseline object is the
+    number of OpenMP THREADS used; on a quota-limited box that is more than the CPUs they get"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def default_cpu_threads():
@@ -246,10 +273,73 @@ def cpu_baseline(curve, k_cpu, seed, threads, key="valid", reuse=None):
     proof, phases = orc.prove(pk, ck, dp.r, dp.s)
     dt = time.time() - t0
     match = bool((proof == gpu_proof).all())
-    return dict(value=dp.nc / dt, unit="constraints/s", cores=orc.threads, kind="port",
+    return dict(value=dp.nc / dt, unit="constraints/s", cores=orc.threads, threads=orc.threads, cpu_quota=cpu_quota(),
+                host_cpus=os.cpu_count(), kind="port",
                 sample=f"SYN(k={k_cpu}) {curve}, {dp.nc} constraints, one proof, {dt:.2f} s; C++ restatement of ark-groth16's "
                        f"CPU algorithm (oracle/g16_oracle.cpp), not ark-groth16 itself",
                 seconds=dt, phases={k_: round(v, 3) for k_, v in phases.items()}, gpu_proof_matches_cpu=match)
+
+
+def run_configs4(args, dist, device, rank, world, local_rank, barrier, dist_wm_ok):
+    """BASELINE.json configs[4]: synthetic R1CS with 2^24 constraints, BLS12-381, MSM bases sharded over the ranks (+ the
+    distributed witness map), same timed bracket as the headline.  Every rank calls this; a rank whose setup fails reports it
+    through an all-reduce BEFORE any data-path collective, so a failure yields {"error": ...} on every rank instead of a hang."""
+    k4 = args.configs4_log2
+    err, p4 = "", None
+    try:
+        p4 = DeviceProver(args.curve, k4, 1, rank, world, local_rank, args.key, dist_wm=dist_wm_ok(world, k4))
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    ok = torch.tensor([0 if err else 1], dtype=torch.int64, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if p4 is not None:
+            p4.close()
+        return {"error": err or "setup failed on another rank"}
+    steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+    proof = None
+    for _ in range(warmup):
+        proof = prove_step(p4, dist, device)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = prove_step(p4, dist, device)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    pt = torch.from_numpy(proof.view(np.int64).copy()).to(device)
+    gathered = [torch.empty_like(pt) for _ in range(world)]
+    dist.all_gather(gathered, pt)
+    same = all(bool((x == gathered[0]).all()) for x in gathered)
+    import hashlib
+
+    res = dict(workload=f"SYN(k={k4}) synthetic R1CS, {p4.nc} constraints, FFT domain 2^{k4}, {args.curve}, full create_proof, MSM bases "
+                        f"sharded over {world} ranks" + (" + distributed witness map" if p4.dwm is not None else " (witness map replicated)"),
+               log2_domain=k4, constraints=p4.nc, n_gpus=world, steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps,
+               value=p4.nc * steps / dt, unit="constraints/s", pk_load_s=round(p4.pk_load_s, 3), ranks_agree_on_proof=same,
+               proof_sha256=hashlib.sha256(proof.tobytes()).hexdigest(), phases_ms_rank0=p4.timings())
+    p4.close()
+    return res
+
+
+def self_launch(n):
+    """re-run this very command line under torch.distributed.run with n ranks on 127.0.0.1 (free port picked here); the
+    children see WORLD_SIZE and take the normal path.  stdout / stderr are inherited: rank 0's JSON line is this process's."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")              # what torchrun would set itself, without its warning on stderr
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -266,6 +356,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--key", choices=["valid", "synthetic"], default=os.environ.get("G16_BENCH_KEY", "valid"),
                     help="valid: CRS of the circuit generated on the GPU (g16_generate_parameters); synthetic: arbitrary distinct points")
+    ap.add_argument("--configs4", choices=["auto", "on", "off"], default=os.environ.get("G16_BENCH_CONFIGS4", "auto"),
+                    help="after the headline line's timed region, also time BASELINE.json configs[4] (2^24 constraints, BLS12-381, MSM bases "
+                         "sharded over the ranks) and report it as the `configs4` field of the same JSON line; auto = when --gpus is 8 "
+                         "and --log2 is the headline 22")
+    ap.add_argument("--configs4-log2", type=int, default=24, help=argparse.SUPPRESS)   # tests shrink it
     ap.add_argument("--sim-shards", type=int, default=0,
                     help="DIAGNOSTIC, not a benchmark: time one rank's share of an N-way sharded proof on a single GPU "
                          "(shard 0 of N, no exchange); the JSON line is tagged and must not be read as throughput")
@@ -273,10 +368,16 @@ def main():
     if args.cpu_log2 <= 0:
         args.cpu_log2 = args.log2
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU, exactly as the
+        # contract's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` would, and hand its exit code back
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; run `python bench.py --gpus N` "
+                 f"(self-launching) or torch.distributed.run with --nproc-per-node equal to --gpus")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
     # test-only knobs (tests/test_gpu_parity.py::test_bench_two_ranks_one_gpu): run the N > 1 code path on a 1-GPU box by
     # putting every rank on device 0 and exchanging over gloo (RCCL refuses two ranks on one device)
@@ -308,6 +409,18 @@ def main():
             torch.cuda.synchronize()
             assert world > 1 or bool((got == probe).all()), "RCCL all_to_all_single returned wrong data"
 
+    # proof that N ranks on N devices took part: every rank contributes (rank, device index, device uuid word, pid) through an
+    # all-gather over the process group itself; rank 0 prints them
+    ranks_seen = None
+    if dist is not None:
+        props = torch.cuda.get_device_properties(local_rank)
+        uu = getattr(props, "uuid", None)
+        uu_word = int.from_bytes(uu.bytes[:7], "little") if uu is not None else -1
+        mine = torch.tensor([rank, local_rank, uu_word, os.getpid()], dtype=torch.int64, device=device)
+        seen = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        ranks_seen = [dict(rank=int(x[0]), device=int(x[1]), device_uuid_word=f"{int(x[2]):014x}", pid=int(x[3])) for x in seen]
+
     gpu = torch.device(f"cuda:{local_rank}")
 
     def barrier():
@@ -315,13 +428,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def dist_wm_ok(n_ranks):
+    def dist_wm_ok(n_ranks, log2=None):
         """the distributed witness map needs a power-of-two rank count <= 16 with ranks^2 | domain size; G16_BENCH_DIST_WM=0
         keeps the replicated map (A/B)"""
         lw = n_ranks.bit_length() - 1
         if n_ranks == 1 and os.environ.get("G16_BENCH_FORCE_DWM"):   # test-only: the distributed-map path with a single rank
             return True
-        return (n_ranks > 1 and (1 << lw) == n_ranks and n_ranks <= 16 and 2 * lw <= args.log2 and
+        return (n_ranks > 1 and (1 << lw) == n_ranks and n_ranks <= 16 and 2 * lw <= (log2 or args.log2) and
                 os.environ.get("G16_BENCH_DIST_WM", "1") != "0")
 
     if args.sim_shards:
@@ -396,6 +509,11 @@ def main():
             assert (pr2 == proof).all(), "host-witness proof differs from the device-witness proof"
             h2d[name] = dict(ms_per_step=1e3 * t_h, value=p.nc / t_h)
 
+    # BASELINE.json configs[4] beside the headline (the driver passes no --log2): the SAME code path at 2^24 constraints, timed
+    # with the same barrier / max-over-ranks bracket, reported as a field -- the headline `value` stays the 2^22 strong-scaling one
+    want_c4 = dist is not None and (args.configs4 == "on" or (args.configs4 == "auto" and world == 8 and args.log2 == 22 and
+                                                                args.curve == "bls12_381"))
+    out = None
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = p.nc * args.steps / dt
@@ -477,6 +595,11 @@ def main():
             "value_survey_8d": (h2d or {}).get("pinned", {}).get("value"),
             "phases_ms_per_step": {k_: round(v / args.steps, 3) for k_, v in phase_acc.items()},
         }
+        if dist is not None:
+            out["rccl_world"] = dist.get_world_size()
+            out["collective_backend"] = "rccl (torch.distributed nccl)" if backend == "nccl" else backend
+            out["ranks"] = ranks_seen
+            out["distinct_devices"] = len({(r_["device"], r_["device_uuid_word"]) for r_ in ranks_seen})
         if os.environ.get("G16_BENCH_PRINT_PROOF"):
             import hashlib
 
@@ -487,6 +610,12 @@ def main():
                                                    reuse=p if args.cpu_log2 == args.log2 else None)
             except Exception as e:  # noqa: BLE001 -- the baseline leg must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(e)}
+    if want_c4:
+        p.close()
+        c4 = run_configs4(args, dist, device, rank, world, local_rank, barrier, dist_wm_ok)
+        if rank == 0:
+            out["configs4"] = c4
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -80,7 +80,13 @@ struct g16_ctx {
         uint64_t n_assign = 0;
         ScalarSort sort_z;
     } prep;
-    void reset_arena() { arena.reset(); prep.valid = false; }
+    // a prepared sort that is being DROPPED (the next call is not the prove_partial it was made for, or a failed call left it
+    // behind) may still be running on stream 2 inside arena buffers: wait for it before the arena is handed out again
+    void reset_arena() {
+        if (prep.valid) (void)hipStreamSynchronize(stream2);
+        arena.reset();
+        prep.valid = false;
+    }
     hipStream_t red[5];   // per MSM: the heavy-bucket combine of G1 MSM k right after its pass ([0..3]); the G2 reduction of a sharded
                           // proof ([4]: short passes, it must not queue behind the witness sort on stream 2)
     Arena arena;
@@ -614,7 +620,8 @@ struct Impl {
         }
         if (skip_b_g1) store_xyzz(out->b_g1, G1X::identity());
         {
-            G16_HIP_TRY(hipEventSynchronize(ctx->ev_done[0]));   // recorded last on stream 1: every G1 copy-out has landed
+            // every queued G1 job's copy-out (the batches are grouped by bucket layout, so h's is not necessarily the last)
+            for (int q = 0; q < njobs; ++q) G16_HIP_TRY(hipEventSynchronize(ctx->ev_done[jobs[q].k]));
             const double t0 = now_ms();
             struct FoldJob { int k; const MsmPlan* plan; uint64_t* dst; };
             const FoldJob fj[4] = {{1, l_covered ? &sort_z.plan : &sort_l.plan, out->l}, {2, &sort_z.plan, out->a}, {3, &sort_z.plan, out->b_g1},
@@ -1694,6 +1701,7 @@ int g16_generate_parameters(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t nu
     if (!ctx->subs.empty())
         return g16_generate_parameters(ctx->subs[0], abc, num_inputs, num_constraints, num_variables, tw, g1_generator, g2_generator, out);
     G16_HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->prep.valid) (void)hipStreamSynchronize(ctx->stream2);   // a dropped prepared sort still owns arena buffers
     ctx->prep.valid = false;   // the generator resets the arena
     try {
         if (ctx->curve == G16_BLS12_381)

@@ -420,30 +420,50 @@ def test_error_paths(env, orc, g):
             prover.witness_map_from_matrices(big, 2, (1 << 28) + 5, ck.z[:3])
 
 
-def test_bench_two_ranks_one_gpu():
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_one_gpu(launcher):
     """bench.py's N > 1 path (sharded key, all-gather of partial records, finalize on every rank, max-over-ranks timing)
     with two ranks on the one visible GPU (gloo carries the exchange; RCCL refuses two ranks per device).  The bench
-    itself asserts that all ranks produce the same proof; here we also require it to equal the single-rank proof."""
+    itself asserts that all ranks produce the same proof; here we also require it to equal the single-rank proof.
+    launcher = "self": exactly `python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE in the environment (bench.py
+    starts its own ranks); "torchrun": the contract's torch.distributed.run command line.  The configs[4] leg (a second, larger
+    instance timed after the headline one, reported as a field) runs here at 2^13 instead of 2^24."""
     import json
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, G16_BENCH_BACKEND="gloo", G16_BENCH_FORCE_DEVICE0="1", G16_BENCH_PRINT_PROOF="1")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(G16_BENCH_BACKEND="gloo", G16_BENCH_FORCE_DEVICE0="1", G16_BENCH_PRINT_PROOF="1")
     port = 29000 + os.getpid() % 2000
-    cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-            str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2", "12", "--no-cpu-baseline"]
+    tail = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2", "12", "--no-cpu-baseline", "--configs4", "on", "--configs4-log2", "13"]
+    if launcher == "self":
+        cmd2 = [sys.executable, os.path.join(root, "bench.py")] + tail
+    else:
+        cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), os.path.join(root, "bench.py")] + tail
     out2 = subprocess.run(cmd2, env=env, capture_output=True, text=True, timeout=600)
     assert out2.returncode == 0, out2.stderr[-2000:]
-    line2 = [l for l in out2.stdout.splitlines() if l.startswith("{")][-1]
-    d2 = json.loads(line2)
-    cmd1 = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log2", "12", "--no-cpu-baseline"]
-    out1 = subprocess.run(cmd1, env=env, capture_output=True, text=True, timeout=600)
+    lines2 = [l for l in out2.stdout.splitlines() if l.startswith("{")]
+    assert len(lines2) == 1, "exactly one JSON line, from rank 0"
+    d2 = json.loads(lines2[-1])
+    base1 = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out1 = subprocess.run(base1 + ["--log2", "12"], env=env, capture_output=True, text=True, timeout=600)
     assert out1.returncode == 0, out1.stderr[-2000:]
     d1 = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and d2["scaling"] == "strong"
     assert d2["proof_sha256"] == d1["proof_sha256"]
+    # the line proves its ranks: world size from the process group, one record per rank gathered through the collective
+    assert d2["rccl_world"] == 2 and [r["rank"] for r in d2["ranks"]] == [0, 1] and len({r["pid"] for r in d2["ranks"]}) == 2
+    assert "rccl_world" not in d1
+    c4 = d2["configs4"]
+    assert "error" not in c4, c4
+    assert c4["log2_domain"] == 13 and c4["n_gpus"] == 2 and c4["ranks_agree_on_proof"] and c4["value"] > 0
+    out13 = subprocess.run(base1 + ["--log2", "13"], env=env, capture_output=True, text=True, timeout=600)
+    assert out13.returncode == 0, out13.stderr[-2000:]
+    d13 = json.loads([l for l in out13.stdout.splitlines() if l.startswith("{")][-1])
+    assert c4["proof_sha256"] == d13["proof_sha256"]
 
 
 def test_bench_rccl_single_rank():
