@@ -93,7 +93,7 @@ class TimingsC(C.Structure):
 EXPORTS = [
     "g16_ctx_create", "g16_ctx_create_multi", "g16_ctx_num_devices", "g16_ctx_destroy", "g16_ctx_stream", "g16_pk_load", "g16_pk_free", "g16_circuit_load", "g16_circuit_free",
     "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_finalize_host", "g16_prove_partial_h", "g16_dwm_create",
-    "g16_dwm_free", "g16_dwm_local_size", "g16_dwm_stage", "g16_dwm_stage_async", "g16_ctx_wm_stream", "g16_prove_partial_prepare", "g16_get_timings", "g16_diag_valu", "g16_witness_map",
+    "g16_dwm_free", "g16_dwm_local_size", "g16_dwm_stage", "g16_dwm_stage_async", "g16_ctx_wm_stream", "g16_prove_partial_prepare", "g16_prove_finalize_prepare", "g16_get_timings", "g16_diag_valu", "g16_witness_map",
     "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
     "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version", "g16_generate_parameters",
     "g16_host_qap_evaluations", "g16_serialized_point_size", "g16_serialize_points", "g16_deserialize_points",
@@ -158,6 +158,7 @@ class Lib:
         c.g16_prove_partial_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_int,
                                           C.POINTER(PartialC)]
         c.g16_prove_partial_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        c.g16_prove_finalize_prepare.argtypes = [C.c_void_p, C.c_void_p, u64p, u64p]
         c.g16_dwm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         c.g16_dwm_free.argtypes = [C.c_void_p]
         c.g16_dwm_free.restype = None

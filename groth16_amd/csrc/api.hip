@@ -93,6 +93,23 @@ struct g16_ctx {
     g16_timings tm;
     EventTimer t_wm, t_prep_h, t_prep_z, t_bucket[5], t_ntt[2];
     hipEvent_t ev_z = nullptr, ev_h = nullptr, ev_wm = nullptr, ev_done[5] = {};
+    // g16_prove_finalize_prepare: the (r, s)-only half of the host glue, running on a host thread (api.hip: FinalizePrep)
+    struct FinPrep {
+        bool valid = false;
+        std::future<void> fut;
+        std::shared_ptr<void> data;
+        const g16_pk* pk = nullptr;
+        uint64_t r[4] = {}, s[4] = {};
+        bool matches(const g16_pk* p, const uint64_t* r_, const uint64_t* s_) const {
+            return valid && pk == p && memcmp(r, r_, 32) == 0 && memcmp(s, s_, 32) == 0;
+        }
+        void drop() {   // wait for a running thread (it reads the key) and forget its result
+            if (valid && fut.valid()) fut.wait();
+            valid = false;
+            data.reset();
+            pk = nullptr;
+        }
+    } finprep;
     void* pinned = nullptr;  // window sums land here (hipHostMalloc)
     size_t pinned_bytes = 0;
     // g16_ctx_create_multi: a multi-device context owns one full context per device and no device state of its own
@@ -676,8 +693,57 @@ struct Impl {
         G1A alpha_g1, beta_g1, delta_g1, a_query0, b_g1_query0;
         G2A beta_g2, delta_g2, b_g2_query0;
     };
-    static int finalize_core(const FixedPoints& pk, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
-                             g16_proof* out, const FixedBaseTable<G1X>* d1 = nullptr, const FixedBaseTable<G2X>* d2 = nullptr) {
+    // prover.rs:76-131 split by what it depends on.  Everything that needs only r, s and the key's eight fixed points -- r delta,
+    // s delta, r s delta, and by linearity of :94 and :114 also s (r delta + a_query[0] + alpha) and r (s delta + b_g1_query[0] + beta)
+    // -- is the PREPARED half: it can run on a host thread while the GPU is still busy with the MSMs (g16_prove starts it at entry;
+    // the sharded path through g16_prove_finalize_prepare).  What is left once the five sums exist: s * sum_a and r * sum_b1 (two
+    // variable-base multiplications, side by side), five additions and the three into_affine inversions.
+    struct FinalizePrep {
+        G1X A0;    // r delta_g1 + a_query[0] + alpha_g1                       (:90-92, :252-270 without the MSM term)
+        G2X B2;    // s delta_g2 + b_g2_query[0] + beta_g2                      (:112-113)
+        G1X C0;    // s A0 + r (s delta_g1 + b_g1_query[0] + beta_g1) - r s delta_g1   (:94, :114, :76; the r term vanishes for r = 0, :98-108)
+        uint32_t rk[Fr::N], sk[Fr::N];
+        bool r_zero;
+    };
+    static FinalizePrep finalize_prepare_core(const FixedPoints& pk, const uint64_t* r_, const uint64_t* s_,
+                                              const FixedBaseTable<G1X>* d1 = nullptr, const FixedBaseTable<G2X>* d2 = nullptr) {
+        FinalizePrep fp;
+        const Fr r = load_pod<Fr>(r_), s = load_pod<Fr>(s_);
+        uint32_t rsk[Fr::N];
+        r.to_canonical(fp.rk);
+        s.to_canonical(fp.sk);
+        (r * s).to_canonical(rsk);
+        fp.r_zero = r.is_zero();
+        const int nb = Fr::Params::BITS;
+        const G1X delta1 = G1X::from_affine(pk.delta_g1);
+        static_assert(Fr::N == 8, "scalars are 8 words: fixed_base.hpp walks 32 bytes / 64 nibbles");
+        auto mul_d1 = [&](const uint32_t* k) { return (d1 && d1->ready()) ? d1->mul(k) : delta1.mul_bits(k, nb); };
+        fp.B2 = (d2 && d2->ready()) ? d2->mul(fp.sk) : G2X::from_affine(pk.delta_g2).mul_bits(fp.sk, nb);
+        fp.B2.add_affine(pk.b_g2_query0);
+        fp.B2.add_affine(pk.beta_g2);
+        fp.A0 = mul_d1(fp.rk);
+        fp.A0.add_affine(pk.a_query0);
+        fp.A0.add_affine(pk.alpha_g1);
+        fp.C0 = mul_window4(fp.A0, fp.sk);
+        if (!fp.r_zero) {
+            G1X b0 = mul_d1(fp.sk);
+            b0.add_affine(pk.b_g1_query0);
+            b0.add_affine(pk.beta_g1);
+            fp.C0.add(mul_window4(b0, fp.rk));
+        }
+        fp.C0.add(mul_d1(rsk).neg());
+        return fp;
+    }
+    // A and C leave through ONE base-field inversion (Montgomery's trick over the two ZZZ), B through its own in Fq2
+    static void two_to_affine(const G1X& p, const G1X& q, G1A* pa, G1A* qa) {
+        if (p.is_identity() || q.is_identity()) { *pa = p.to_affine(); *qa = q.to_affine(); return; }
+        const Fq inv = (p.zzz * q.zzz).inverse();
+        const Fq ip = inv * q.zzz, iq = inv * p.zzz;   // 1/ZZZ_p, 1/ZZZ_q
+        const Fq zp = ip * p.zz, zq = iq * q.zz;       // 1/Z
+        *pa = {p.x * zp.sqr(), p.y * ip};
+        *qa = {q.x * zq.sqr(), q.y * iq};
+    }
+    static int finalize_finish(const FinalizePrep& fp, const g16_partial* parts, int n_parts, g16_proof* out) {
         if (n_parts < 1) return G16_ERR_BAD_ARG;
         G1X h_acc = G1X::identity(), l_acc = G1X::identity(), a_msm = G1X::identity(), b1_msm = G1X::identity();
         G2X b2_msm = G2X::identity();
@@ -688,73 +754,79 @@ struct Impl {
             b1_msm.add(load_xyzz<G1X>(parts[i].b_g1));
             b2_msm.add(load_xyzz<G2X>(parts[i].b_g2));
         }
-        const Fr r = load_pod<Fr>(r_), s = load_pod<Fr>(s_);
-        uint32_t rk[Fr::N], sk[Fr::N], rsk[Fr::N];
-        r.to_canonical(rk);
-        s.to_canonical(sk);
-        (r * s).to_canonical(rsk);
-        const int nb = Fr::Params::BITS;
-        const G1X delta1 = G1X::from_affine(pk.delta_g1);
-        static_assert(Fr::N == 8, "scalars are 8 words: fixed_base.hpp walks 32 bytes / 64 nibbles");
-        auto mul_d1 = [&](const uint32_t* k) { return (d1 && d1->ready()) ? d1->mul(k) : delta1.mul_bits(k, nb); };
-        // three independent chains of scalar multiplications (the only non-trivial host work): run them on host threads
-        // B in G2:  s*delta_g2 + b_g2_query[0] + msm + beta_g2                       (:112-113)
+        // B in G2 and r * sum_b1 on two host threads, s * sum_a here
         auto fut_b2 = std::async(std::launch::async, [&]() {
-            G2X g2_b = (d2 && d2->ready()) ? d2->mul(sk) : G2X::from_affine(pk.delta_g2).mul_bits(sk, nb);
-            g2_b.add_affine(pk.b_g2_query0);
+            G2X g2_b = fp.B2;
             g2_b.add(b2_msm);
-            g2_b.add_affine(pk.beta_g2);
-            return g2_b;
+            return g2_b.to_affine();                                            // :129
         });
-        // r * B in G1, skipped when r == 0                                            (:98-108, :114)
-        auto fut_rb1 = std::async(std::launch::async, [&]() {
-            G1X g1_b = G1X::identity();
-            if (!r.is_zero()) {
-                g1_b = mul_d1(sk);
-                g1_b.add_affine(pk.b_g1_query0);
-                g1_b.add(b1_msm);
-                g1_b.add_affine(pk.beta_g1);
-            }
-            return mul_window4(g1_b, rk);
-        });
-        // g_a = r*delta_g1 + a_query[0] + msm + alpha_g1   (calculate_coeff, :90-92, :252-270), then s*g_a (:94)
-        G1X g_a = mul_d1(rk);
-        g_a.add_affine(pk.a_query0);
+        const bool need_rb1 = !fp.r_zero && !b1_msm.is_identity();              // r == 0: :98-108
+        std::future<G1X> fut_rb1;
+        if (need_rb1) fut_rb1 = std::async(std::launch::async, [&]() { return mul_window4(b1_msm, fp.rk); });
+        G1X g_a = fp.A0;                                                        // :90-92
         g_a.add(a_msm);
-        g_a.add_affine(pk.alpha_g1);
-        const G1X s_g_a = mul_window4(g_a, sk);
-        const G1X r_s_delta_g1 = mul_d1(rsk);                                   // :76
-        const G1X r_g1_b = fut_rb1.get();
-        const G2X g2_b = fut_b2.get();
-        G1X g_c = s_g_a;                                                        // :119-124
-        g_c.add(r_g1_b);
-        g_c.add(r_s_delta_g1.neg());
+        G1X g_c = fp.C0;                                                        // :119-124, regrouped
+        g_c.add(mul_window4(a_msm, fp.sk));
         g_c.add(l_acc);
         g_c.add(h_acc);
-        const G1A pa = g_a.to_affine();                                         // :127-131
-        const G2A pb = g2_b.to_affine();
-        const G1A pc = g_c.to_affine();
+        if (need_rb1) g_c.add(fut_rb1.get());
+        G1A pa, pc;
+        two_to_affine(g_a, g_c, &pa, &pc);                                      // :128, :130
+        const G2A pb = fut_b2.get();
         memset(out, 0, sizeof(*out));
         memcpy(out->a, &pa, sizeof(pa));
         memcpy(out->b, &pb, sizeof(pb));
         memcpy(out->c, &pc, sizeof(pc));
         return G16_OK;
     }
+    static int finalize_core(const FixedPoints& pk, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
+                             g16_proof* out, const FixedBaseTable<G1X>* d1 = nullptr, const FixedBaseTable<G2X>* d2 = nullptr) {
+        if (n_parts < 1) return G16_ERR_BAD_ARG;
+        return finalize_finish(finalize_prepare_core(pk, r_, s_, d1, d2), parts, n_parts, out);
+    }
+    static FixedPoints fixed_points(const DevicePk<C>* pk) {
+        return {pk->alpha_g1, pk->beta_g1, pk->delta_g1, pk->a_query0, pk->b_g1_query0, pk->beta_g2, pk->delta_g2, pk->b_g2_query0};
+    }
+    static void ensure_delta_tables(const DevicePk<C>* pk) {   // built on the second proof over a key (32 * 256 additions each)
+        std::lock_guard<std::mutex> lk(pk->tab_mu);
+        if (!pk->delta2_tab.ready() && ++pk->finalize_calls >= 2) {
+            auto f1 = std::async(std::launch::async, [&]() { pk->delta1_tab.build(G1X::from_affine(pk->delta_g1)); });
+            pk->delta2_tab.build(G2X::from_affine(pk->delta_g2));
+            f1.get();
+        }
+    }
+    // start the prepared half on a host thread; g16_prove_finalize over the same (key, r, s) picks it up
+    static int prove_finalize_prepare(g16_ctx* ctx, const g16_pk* pkh, const uint64_t* r_, const uint64_t* s_) {
+        const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
+        ctx->finprep.drop();
+        auto data = std::make_shared<FinalizePrep>();
+        ctx->finprep.data = data;
+        ctx->finprep.pk = pkh;
+        memcpy(ctx->finprep.r, r_, 32);
+        memcpy(ctx->finprep.s, s_, 32);
+        const uint64_t* rr = ctx->finprep.r;
+        const uint64_t* ss = ctx->finprep.s;
+        ctx->finprep.fut = std::async(std::launch::async, [pk, data, rr, ss]() {
+            ensure_delta_tables(pk);
+            *data = finalize_prepare_core(fixed_points(pk), rr, ss, &pk->delta1_tab, &pk->delta2_tab);
+        });
+        ctx->finprep.valid = true;
+        return G16_OK;
+    }
     static int prove_finalize(g16_ctx* ctx, const g16_pk* pkh, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
                               g16_proof* out) {
         const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
         const double t0 = now_ms();
-        const FixedPoints fp = {pk->alpha_g1, pk->beta_g1, pk->delta_g1, pk->a_query0, pk->b_g1_query0, pk->beta_g2, pk->delta_g2,
-                                pk->b_g2_query0};
-        {
-            std::lock_guard<std::mutex> lk(pk->tab_mu);
-            if (!pk->delta2_tab.ready() && ++pk->finalize_calls >= 2) {
-                auto f1 = std::async(std::launch::async, [&]() { pk->delta1_tab.build(G1X::from_affine(pk->delta_g1)); });
-                pk->delta2_tab.build(G2X::from_affine(pk->delta_g2));
-                f1.get();
-            }
+        if (n_parts < 1) return G16_ERR_BAD_ARG;
+        if (ctx->finprep.matches(pkh, r_, s_)) {   // prepared while the GPU was busy
+            ctx->finprep.fut.get();
+            const std::shared_ptr<void> keep = ctx->finprep.data;
+            ctx->finprep.valid = false;
+            G16_TRY(finalize_finish(*static_cast<const FinalizePrep*>(keep.get()), parts, n_parts, out));
+        } else {
+            ensure_delta_tables(pk);
+            G16_TRY(finalize_core(fixed_points(pk), parts, n_parts, r_, s_, out, &pk->delta1_tab, &pk->delta2_tab));
         }
-        G16_TRY(finalize_core(fp, parts, n_parts, r_, s_, out, &pk->delta1_tab, &pk->delta2_tab));
         const double dt = now_ms() - t0;
         ctx->tm.finish_ms += dt;
         ctx->tm.total_ms += dt;
@@ -1126,17 +1198,26 @@ static bool serial_loads(const g16_ctx* ctx) {
 template <class B30>
 static void diag_counts(g16_diag* out) {
     constexpr int NL = B30::NL;
-    int relax1 = 0, relax2 = 0;   // relaxed columns before a second sweep / before the reduction after two sweeps
-    for (int c = 0; c + 1 < 2 * NL; ++c) {
-        if (2 * B30::col_count(c) > G16_RELAX_LIMIT) ++relax1;
-        if (3 * B30::col_count(c) > G16_RELAX_LIMIT) ++relax2;
-    }
-    const double mul = 2.0 * NL * NL + relax1, sqr = NL * (NL + 1) / 2.0 + NL * NL + relax1;
-    const double pair_mul = 3.0 * NL * NL + relax1 + relax2;   // two product sweeps + one reduction per lane
+    int relax[5] = {0, 0, 0, 0, 0};   // relax[k]: columns relaxed when k sweeps are in and one more (a sweep or the reduction) follows
+    for (int c = 0; c + 1 < 2 * NL; ++c)
+        for (int k = 1; k <= 4; ++k)
+            if ((k + 1) * B30::col_count(c) > G16_RELAX_LIMIT) ++relax[k];
+    const double mul = 2.0 * NL * NL + relax[1], sqr = NL * (NL + 1) / 2.0 + NL * NL + relax[1];
+    const double two_sweeps = 3.0 * NL * NL + relax[1] + relax[2];   // two product sweeps + ONE reduction: a lane's Fq2 product; Fp30::mul_sub_cols
+    const double four_sweeps = 5.0 * NL * NL + relax[1] + relax[2] + relax[3] + relax[4];   // Fp2p30::pair_mul_sub
     out->limbs = NL;
     out->mads_per_product = mul;
-    out->mads_per_add_g1 = 8 * mul + 2 * sqr;                  // madd-2008-s: U2 S2 PPP Q R(Q-X3) Y1*PPP ZZ*PP ZZZ*PPP + PP, R^2
-    out->mads_per_add_g2 = 2 * (8 * pair_mul + 2 * mul);       // per lane 8 pair products + 2 pair squarings (one product each)
+    // madd-2008-s as the bucket pass runs it (AccParked, fp30.hpp): U2 S2 PPP Q ZZ*PP ZZZ*PPP + the squarings PP, R^2 + Y3 = R (Q - X3) - Y1 PPP
+    // under one reduction (the register-resident Acc30 of the other kernels spends two products on Y3)
+    const bool fused_g1 = Fp30<typename B30::Params_t>::ACC_PARKED, fused_g2 = Fp2p30<typename B30::Params_t>::ACC_PARKED;
+#ifdef G16_NO_MUL_SUB_FUSED
+    const bool fused = false;
+#else
+    const bool fused = true;
+#endif
+    out->mads_per_add_g1 = (fused && fused_g1) ? 6 * mul + 2 * sqr + two_sweeps : 8 * mul + 2 * sqr;
+    // per lane of the pair: pair products (two sweeps each), two pair squarings (one product each), Y3 as four sweeps + one reduction
+    out->mads_per_add_g2 = 2 * ((fused && fused_g2) ? 6 * two_sweeps + 2 * mul + four_sweeps : 8 * two_sweeps + 2 * mul);
 }
 
 extern "C" {
@@ -1238,6 +1319,7 @@ void g16_ctx_destroy(g16_ctx* ctx) {
         delete ctx;
         return;
     }
+    ctx->finprep.drop();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
@@ -1330,6 +1412,7 @@ void g16_pk_free(g16_pk* pk) {
         delete pk;
         return;
     }
+    if (pk->ctx->finprep.pk == pk) pk->ctx->finprep.drop();   // a prepared finalize half may still be reading the key's fixed points
     (void)hipSetDevice(pk->ctx->device);
     if (pk->curve == G16_BLS12_381) Impl<Bls12_381>::pk_free(static_cast<DevicePk<Bls12_381>*>(pk->dp));
     else Impl<Bn254>::pk_free(static_cast<DevicePk<Bn254>*>(pk->dp));
@@ -1394,11 +1477,18 @@ void g16_circuit_free(g16_circuit* c) {
 
 uint64_t g16_circuit_domain_size(const g16_circuit* c) { return c ? c->domain_size : 0; }
 
+// A key / circuit may be used by ANY single-device context on the GPU it was loaded on: the device data is read-only during a
+// proof, everything a proof writes (arena, streams, events, pinned buffer, timers) belongs to the calling context.  Two contexts
+// on one GPU proving side by side over one key is the throughput mode (the tail of one proof under the passes of the other).
+static bool usable_on(const g16_ctx* owner, const g16_ctx* ctx) {
+    return owner == ctx || (owner && ctx && owner->subs.empty() && ctx->subs.empty() && owner->device == ctx->device && owner->curve == ctx->curve);
+}
+
 int g16_prove_partial(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment, uint64_t n_assign,
                       int assignment_on_device, int skip_b_g1, g16_partial* out) {
     if (!ctx || !pk || !circuit || !full_assignment || !out) return G16_ERR_BAD_ARG;
     if (pk->curve != ctx->curve || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
-    if (!ctx->subs.empty() || pk->ctx != ctx || circuit->ctx != ctx) return G16_ERR_BAD_ARG;   // multi-device contexts: g16_prove
+    if (!ctx->subs.empty() || !usable_on(pk->ctx, ctx) || !usable_on(circuit->ctx, ctx)) return G16_ERR_BAD_ARG;   // multi-device contexts: g16_prove
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, out));
 }
@@ -1412,6 +1502,16 @@ int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts,
         return g16_prove_finalize(ctx->subs[0], pk->subs[0], parts, n_parts, r, s, out);
     }
     G16_DISPATCH(ctx->curve, I::prove_finalize(ctx, pk, parts, n_parts, r, s, out));
+}
+
+int g16_prove_finalize_prepare(g16_ctx* ctx, const g16_pk* pk, const uint64_t r[4], const uint64_t s[4]) {
+    if (!ctx || !pk || !r || !s) return G16_ERR_BAD_ARG;
+    if (pk->curve != ctx->curve) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) {
+        if (pk->subs.empty()) return G16_ERR_BAD_ARG;
+        return g16_prove_finalize_prepare(ctx->subs[0], pk->subs[0], r, s);
+    }
+    G16_DISPATCH(ctx->curve, I::prove_finalize_prepare(ctx, pk, r, s));
 }
 
 int g16_finalize_host(int curve, const g16_pk_view* fixed, const g16_partial* parts, int n_parts, const uint64_t r[4], const uint64_t s[4],
@@ -1433,6 +1533,7 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
             for (g16_ctx* sub : ctx->subs) if (sub->device != ctx->subs[0]->device) return G16_ERR_BAD_ARG;
         const double t0 = now_ms();
         std::vector<g16_partial> parts((size_t)n);
+        if (!pk->subs.empty()) (void)g16_prove_finalize_prepare(ctx->subs[0], pk->subs[0], r, s);   // host glue under the GPU work
         if (pk->dist_n && (circuit->dist.empty() || pk->dist_n != circuit->domain_size)) {
             g_last_error = "the key's h_query does not belong to this circuit's domain (h_query must hold domain_size - 1 bases)";
             return G16_ERR_BAD_LENGTH;
@@ -1543,15 +1644,18 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
         ctx->tm.total_ms = now_ms() - t0;
         return rc;
     }
-    int rc = g16_prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, &part);
+    if (!ctx || !pk) return G16_ERR_BAD_ARG;
+    int rc = g16_prove_finalize_prepare(ctx, pk, r, s);   // the (r, s)-only host glue runs while the GPU works
     if (rc) return rc;
+    rc = g16_prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, &part);
+    if (rc) { ctx->finprep.drop(); return rc; }
     return g16_prove_finalize(ctx, pk, &part, 1, r, s, out);
 }
 
 int g16_prove_partial_prepare(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const uint64_t* full_assignment_dev, uint64_t n_assign) {
     if (!ctx || !pk || !circuit || !full_assignment_dev) return G16_ERR_BAD_ARG;
     if (pk->curve != ctx->curve || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
-    if (!ctx->subs.empty() || pk->ctx != ctx || circuit->ctx != ctx) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty() || !usable_on(pk->ctx, ctx) || !usable_on(circuit->ctx, ctx)) return G16_ERR_BAD_ARG;
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::prove_partial_prepare(ctx, pk, circuit, full_assignment_dev, n_assign));
 }
@@ -1560,7 +1664,7 @@ int g16_prove_partial_h(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circu
                         int assignment_on_device, const uint64_t* h_dev, uint64_t h_len, int skip_b_g1, g16_partial* out) {
     if (!ctx || !pk || !circuit || !full_assignment || !h_dev || !out) return G16_ERR_BAD_ARG;
     if (pk->curve != ctx->curve || circuit->curve != ctx->curve) return G16_ERR_BAD_ARG;
-    if (!ctx->subs.empty() || pk->ctx != ctx || circuit->ctx != ctx) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty() || !usable_on(pk->ctx, ctx) || !usable_on(circuit->ctx, ctx)) return G16_ERR_BAD_ARG;
     G16_HIP_TRY(hipSetDevice(ctx->device));
     G16_DISPATCH(ctx->curve, I::prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, out,
                                               reinterpret_cast<const typename I::Fr*>(h_dev), h_len));

@@ -23,6 +23,7 @@ namespace g16 {
 
 template <class P>
 struct Fp30 {
+    typedef P Params_t;
     static constexpr int NL = P::NL30;
     static constexpr int NW = P::N;  // 32-bit words of the packed form
     static constexpr uint32_t MASK = (1u << 30) - 1u;
@@ -240,6 +241,14 @@ struct Fp30 {
         return mul_sub_cols<uint64_t>(a, b, c, d);
 #endif
     }
+    // the fused form unconditionally: AccParked (bucket pass) has the registers for it -- its accumulator is not in them
+    G16_HD static Fp30 mul_sub_fused(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) {
+#ifdef G16_NO_MUL_SUB_FUSED
+        return a.mul(b).template sub<2>(c.mul(d));
+#else
+        return mul_sub_cols<uint64_t>(a, b, c, d);
+#endif
+    }
     G16_HD Fp30 sqr() const {
 #if defined(G16_FP30_OUTLINE) || defined(G16_FP30_NO_SQR)
         return mul(*this);
@@ -299,6 +308,10 @@ struct Fp30 {
 #endif
     static constexpr int ACC_MIN_WAVES = G16_ACC_MIN_WAVES;
     static constexpr bool ACC_PREFETCH = true;
+#ifndef G16_G1_PARKED
+#define G16_G1_PARKED 1
+#endif
+    static constexpr bool ACC_PARKED = G16_G1_PARKED != 0;   // bucket pass: accumulator coordinates in LDS (AccParked)
     // ---- bucket-kernel hooks: one lane per task
     static constexpr int LANES_PER_TASK = 1;
     template <class A>
@@ -464,11 +477,14 @@ struct Fp2x30 {
     G16_HD Std to_packed() const { return {c0.to_packed(), c1.to_packed()}; }
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD static Fp2x30 mul_sub(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return a.mul(b).template sub<KM>(c.mul(d)); }
+    G16_HD static Fp2x30 mul_sub_fused(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return mul_sub(a, b, c, d); }
     G16_HD Fp2x30 settle() const { return *this; }
     G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     typedef Fp2x30 Raw;
     static constexpr int ACC_MIN_WAVES = 1;
     static constexpr bool ACC_PREFETCH = false;
+    static constexpr bool ACC_PARKED = false;
+    static constexpr int PREFIX_LIMBS = 2 * B::NL;
     // ---- bucket-kernel hooks: one lane per task
     static constexpr int LANES_PER_TASK = 1;
     template <class A>
@@ -524,6 +540,7 @@ struct Fp2k30 {
     // product outputs < 6p -> subtract them with K = 8 (16 when doubled); x, y are settled below 2p
     static constexpr int KM = 8, K2M = 16, KX = 2, KY = 2;
     G16_HD static Fp2k30 mul_sub(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return a.mul(b).template sub<KM>(c.mul(d)); }
+    G16_HD static Fp2k30 mul_sub_fused(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return mul_sub(a, b, c, d); }
     G16_HD Fp2k30 settle() const { return {c0.weak_reduce32(), c1.weak_reduce32()}; }
     G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     typedef Fp2x30<P> Raw;
@@ -532,6 +549,8 @@ struct Fp2k30 {
 #endif
     static constexpr int ACC_MIN_WAVES = G16_G2_MIN_WAVES;
     static constexpr bool ACC_PREFETCH = false;
+    static constexpr bool ACC_PARKED = false;
+    static constexpr int PREFIX_LIMBS = 2 * B::NL;
     // ---- bucket-kernel hooks: one lane per task
     static constexpr int LANES_PER_TASK = 1;
     template <class A>
@@ -634,6 +653,15 @@ struct Fp2p30 {
         return a.mul(b).template sub<2>(c.mul(d));
 #endif
     }
+    // Round 4: with the accumulator parked in LDS (AccParked) the four-sweep form fits: 23.6 vs 24.0 ms per 2^22-point G2 pass on one
+    // box (profiles/r04_ab_parked_accumulator.txt), where round 2 measured it 5 % slower inside the register-resident Acc30
+    G16_HD static Fp2p30 mul_sub_fused(const Fp2p30& a, const Fp2p30& b, const Fp2p30& c, const Fp2p30& d) {
+#ifdef G16_NO_MUL_SUB_FUSED
+        return a.mul(b).template sub<2>(c.mul(d));
+#else
+        return {pair_mul_sub(lane_hi(), a.c, swap(a.c), b.c, swap(b.c), c.c, swap(c.c), d.c, swap(d.c))};
+#endif
+    }
     G16_HD static Fp2p30 zero() { return {B::zero()}; }
     G16_HD static Fp2p30 one() { return {lane_hi() ? B::zero() : B::one()}; }
     G16_HD Fp2p30 add(const Fp2p30& o) const { return {c.add(o.c)}; }
@@ -673,6 +701,10 @@ struct Fp2p30 {
 #endif
     static constexpr int ACC_MIN_WAVES = G16_PAIR_MIN_WAVES;
     static constexpr bool ACC_PREFETCH = G16_PAIR_PREFETCH;
+#ifndef G16_PAIR_PARKED
+#define G16_PAIR_PARKED 1
+#endif
+    static constexpr bool ACC_PARKED = G16_PAIR_PARKED != 0;   // bucket pass: accumulator coordinates in LDS (AccParked)
     // ---- bucket-kernel hooks: two lanes per task, each touching only its half of every Fq2 value
     static constexpr int LANES_PER_TASK = 2;
     template <class A>
@@ -883,6 +915,86 @@ struct Acc30 {
         if (inf) return XYZZ<StdF>::identity();
         return {x.to_std(), y.to_std(), zz.to_std(), zzz.to_std()};
     }
+};
+
+// The same accumulator with its four coordinates PARKED outside the register file (the bucket kernels: LDS, one column of words per
+// lane).  Why: one lazy product already needs two operands, 2 NL 64-bit columns and the reduction's scratch -- ~110 of the 256
+// registers that keep two waves per SIMD -- and madd-2008-s touches every coordinate exactly twice with a long gap in between
+// (zz, zzz: first and last product; x, y: the differences and one late product).  Held in registers the allocator spilled them to
+// HBM-backed scratch instead (G2 lane pair: 392 B per lane, ~2.3 GB each way per 2^22-point launch, with 0 bytes of LDS in use);
+// parked, a coordinate costs 13 LDS words read twice and written once per addition and the live set of the formula is
+// R, PP, PPP, Q plus the operand being fetched.  The products are issued so that each coordinate's second use follows as early
+// as the data flow allows (zz * PP right after PP, zzz * PPP right after PPP).
+// Store: F ld(int which) / void st(int which, const F&); every ld is a fresh read (the store orders it against its own st's).
+// Same formulas, same K constants and therefore the same bounds as Acc30::add_affine (BoundF runs this code too).
+template <class F, class Store>
+struct AccParked {
+    enum { CX = 0, CY = 1, CZZ = 2, CZZZ = 3 };
+    Store s;
+    bool inf;
+
+    G16_HD void set_identity() { inf = true; }
+    G16_HD Acc30<F> gather() const {
+        Acc30<F> a;
+        a.inf = inf;
+        if (inf) { a.x = a.y = a.zz = a.zzz = F::zero(); return a; }
+        a.x = s.ld(CX); a.y = s.ld(CY); a.zz = s.ld(CZZ); a.zzz = s.ld(CZZZ);
+        return a;
+    }
+    G16_HD void scatter(const Acc30<F>& a) {
+        inf = a.inf;
+        if (inf) return;
+        s.st(CX, a.x); s.st(CY, a.y); s.st(CZZ, a.zz); s.st(CZZZ, a.zzz);
+    }
+    // mdbl-2008-s-1 on an affine point (px, py < 2p), parked like the addition: V and W go straight to their slots
+    G16_HD void set_double(const F& px, const F& py) {
+        const F U = py.dbl();                     // < 4p
+        if (U.is_zero_exact()) { inf = true; return; }
+        s.st(CZZ, U.sqr());
+        s.st(CZZZ, U.mul(s.ld(CZZ)));
+        const F S = px.mul(s.ld(CZZ));
+        const F X2 = px.sqr();
+        const F M = X2.dbl().add(X2);             // < 3 * (square bound)
+        const F X3 = M.sqr().template sub<F::K2M>(S.dbl()).settle();
+        s.st(CX, X3);
+        s.st(CY, F::mul_sub(M, S.template sub<F::KX>(X3), py, s.ld(CZZZ)).settle());   // (cold path: two plain products, fewer registers)
+        inf = false;
+    }
+    // madd-2008-s: this += (px, py), affine, px, py < 2p, not the identity
+    G16_HD void add_affine(const F& px, const F& py) {
+        if (inf) {
+            s.st(CX, px); s.st(CY, py); s.st(CZZ, F::one()); s.st(CZZZ, F::one());
+            inf = false;
+            return;
+        }
+        const F U2 = px.mul(s.ld(CZZ));
+        const F S2 = py.mul(s.ld(CZZZ));
+        const F Pd = U2.template sub<F::KX>(s.ld(CX));
+        const F R = S2.template sub<F::KY>(s.ld(CY));
+        if (Pd.maybe_zero()) {
+            if (Pd.is_zero_exact()) {   // P == +-Q: doubling (the sum is 2 (px, py), whatever the accumulator's scale) or cancellation
+                if (R.is_zero_exact()) set_double(px, py);
+                else inf = true;
+                return;
+            }
+        }
+        const F PP = Pd.sqr();
+        s.st(CZZ, s.ld(CZZ).mul(PP));
+        const F PPP = Pd.mul(PP);
+        s.st(CZZZ, s.ld(CZZZ).mul(PPP));
+        const F Q = s.ld(CX).mul(PP);
+        const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
+        s.st(CX, X3);
+        s.st(CY, F::mul_sub_fused(R, Q.template sub<F::KX>(X3), s.ld(CY), PPP).settle());
+    }
+};
+
+// host-side Store for the self-tests: plain memory
+template <class F>
+struct ParkedArrayStore {
+    F v[4];
+    G16_HD F ld(int k) const { return v[k]; }
+    G16_HD void st(int k, const F& a) { v[k] = a; }
 };
 
 }  // namespace g16

@@ -71,6 +71,14 @@ struct BoundF {
     BoundF mul(const BoundF& o) const { return ctx().pair ? product(b, o.b > 16.0 ? o.b : 16.0, b * o.b + b * 16.0) : product(b, o.b, b * o.b); }
     BoundF sqr() const { return ctx().pair ? product(2.0 * b, b + 16.0, 2.0 * b * (b + 16.0)) : product(b, b, b * b); }
     static BoundF mul_sub(const BoundF& a, const BoundF& bb, const BoundF& c, const BoundF& d) { return a.mul(bb).template sub<2>(c.mul(d)); }
+    // the fused a b - c d (one reduction over all sweeps): d enters as 2p - d (< 2p needed); one lane: a b + c (2p - d); lane pair:
+    // a0 b0 + a1 (16p - b1) + c0 (2p - d0) + c1 d1  resp.  a0 b1 + a1 b0 + c0 (2p - d1) + c1 (2p - d0)
+    static BoundF mul_sub_fused(const BoundF& a, const BoundF& bb, const BoundF& c, const BoundF& d) {
+        check(d.b <= 2.0 - 1e-3, "mul_sub_fused: d not below 2p");
+        const double A = a.b > c.b ? a.b : c.b;
+        if (ctx().pair) return product(A, bb.b > 16.0 ? bb.b : 16.0, a.b * bb.b + a.b * (bb.b > 16.0 ? bb.b : 16.0) + 4.0 * c.b);
+        return product(A, bb.b > 2.0 ? bb.b : 2.0, a.b * bb.b + 2.0 * c.b);
+    }
     BoundF settle() const { return *this; }
     bool maybe_zero() const { check(b < 16.0, "zero test on a value not below 16p"); return false; }
     bool is_zero_exact() const { check(b < 16.0, "zero test on a value not below 16p"); return false; }
@@ -446,6 +454,20 @@ struct SelfTest {
             for (int k = 0; k < 4; ++k) if (v[k] > mx[k]) mx[k] = v[k];
         }
         if (c.fail) { *report = c.fail; return 1; }
+        {   // the parked form (bucket pass): same formulas in another order -- same preconditions, same fixed point
+            AccParked<B, ParkedArrayStore<B>> pk;
+            pk.set_identity();
+            for (int it = 0; it < 200; ++it) {
+                pk.add_affine(B{1.0}, B{2.0});
+                const A g = pk.gather();
+                const double v[4] = {g.x.b, g.y.b, g.zz.b, g.zzz.b};
+                for (int k = 0; k < 4; ++k) if (v[k] > mx[k]) mx[k] = v[k];
+            }
+            AccParked<B, ParkedArrayStore<B>> pd;
+            pd.set_identity();
+            pd.set_double(B{1.0}, B{2.0});
+            if (c.fail) { *report = c.fail; return 7; }
+        }
         // the invariants fp30.hpp documents for the accumulator
         if (!(mx[0] < 7.5 && mx[1] < 3.5 && mx[2] < 1.8 && mx[3] < 1.8)) { *report = "accumulator bounds above the documented ones"; return 2; }
         // full additions, doublings, mixed doubling on accumulators at those bounds (reduction kernels, heavy combine, P + P branch)
@@ -554,12 +576,16 @@ struct SelfTest {
             if (round == 2) { seq[1] = seq[0].neg(); }                    // P - P -> identity, then keep adding
             if (round == 3) { seq[3] = seq[0]; seq[2] = seq[1]; seq[5] = seq[4].neg(); }
             Acc30<F30> acc = Acc30<F30>::identity();
+            AccParked<F30, ParkedArrayStore<F30>> park;   // the bucket pass's form: coordinates outside the registers, re-ordered products
+            park.set_identity();
             G1X ref = G1X::identity();
             for (size_t i = 0; i < seq.size(); ++i) {
                 acc.add_affine(to30(seq[i].x), to30(seq[i].y));
+                park.add_affine(to30(seq[i].x), to30(seq[i].y));
                 ref.add_affine(seq[i]);
                 const G1A got = acc.to_std().to_affine(), want = ref.to_affine();
                 if (!(got == want)) return 100 + round * 100 + (int)i;
+                if (!(park.gather().to_std().to_affine() == want)) return 5000 + round * 100 + (int)i;
             }
         }
         // ---- full additions / doublings / small multiples / packed storage of the lazy accumulator (G1)
@@ -624,6 +650,13 @@ struct SelfTest {
             if (!(FP::pair_mul(true, a1, a0, b1, b0).to_std() == want_m.c1)) return 37;
             if (!(FP::pair_sqr(false, a0, a1).to_std() == want_s.c0)) return 38;
             if (!(FP::pair_sqr(true, a1, a0).to_std() == want_s.c1)) return 39;
+            // the four-sweep a b - c d of the parked bucket accumulator (d canonical: < 2p as the routine requires)
+            const Fq2 z = {rand_fq(st), rand_fq(st)}, w = {rand_fq(st), rand_fq(st)};
+            const F30 c0 = to30(z.c0).add(b0), c1 = to30(z.c1).add(b1), d0 = to30(w.c0), d1 = to30(w.c1);   // c lazy: z + y
+            const Fq2 want_ms = x * y - (z + y) * w;
+            if (!(FP::pair_mul_sub(false, a0, a1, b0, b1, c0, c1, d0, d1).to_std() == want_ms.c0)) return 3601;
+            if (!(FP::pair_mul_sub(true, a1, a0, b1, b0, c1, c0, d1, d0).to_std() == want_ms.c1)) return 3602;
+            if (!(F30::template mul_sub_cols<uint64_t>(a0, b0, c0, d0).to_std() == x.c0 * y.c0 - (z.c0 + y.c0) * w.c0)) return 3603;
         }
         // ---- the bucket kernel's Karatsuba Fq2 (register-passed products, settled accumulator)
         typedef Fp2k30<typename Fq::Params> FK;
@@ -656,12 +689,16 @@ struct SelfTest {
                 if (round == 1) { seq[1] = seq[0]; }
                 if (round == 2) { seq[1] = seq[0].neg(); seq[4] = seq[3]; }
                 Acc30<F230> acc = Acc30<F230>::identity();
+                AccParked<F230, ParkedArrayStore<F230>> park2;
+                park2.set_identity();
                 G2X ref = G2X::identity();
                 for (size_t i = 0; i < seq.size(); ++i) {
                     const F230 px = {to30(seq[i].x.c0), to30(seq[i].x.c1)}, py = {to30(seq[i].y.c0), to30(seq[i].y.c1)};
                     acc.add_affine(px, py);
+                    park2.add_affine(px, py);
                     ref.add_affine(seq[i]);
                     if (!(acc.to_std().to_affine() == ref.to_affine())) return 1000 + round * 100 + (int)i;
+                    if (!(park2.gather().to_std().to_affine() == ref.to_affine())) return 5500 + round * 100 + (int)i;
                 }
                 {   // the same sequence through the Karatsuba accumulator used by the G2 bucket kernel
                     Acc30<FK> ak = Acc30<FK>::identity();

@@ -358,6 +358,41 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(con
 // `bases` hold canonical x*R', y*R' packed in 32-bit words (convert_bases30_kernel).
 // DIRECT (batched-affine plan): the walk is over the level-R list itself -- slot e holds an affine point (or the identity),
 // bucket b owns slots [offsets[b] >> off_shift, offsets[b + 1] >> off_shift) -- instead of over sorted entry words.
+// The accumulator's coordinates in LDS (AccParked, fp30.hpp): value v, limb i of lane t.  Limbs are grouped in fours so that a
+// coordinate moves as ds_read_b128 / ds_write_b128 (each lane its own 16 bytes, consecutive lanes consecutive: conflict-free) plus
+// single words for the NL mod 4 tail rows.  4 * NL * 64 words per 64-lane workgroup: 13 KB (NL = 13), i.e. 104 of the CU's 160 KB at
+// two waves per SIMD (eight workgroups per CU).
+template <class F30>
+struct LdsAccStore {
+    static constexpr int NL = F30::PREFIX_LIMBS;
+    static constexpr int QUADS = NL / 4, TAIL = NL % 4;
+    static constexpr int WORDS_PER_VALUE = NL * ACC_THREADS;
+    uint32_t* quad;   // lds + 4 * lane
+    uint32_t* tail;   // lds + 4 * QUADS * ACC_THREADS + lane
+    __device__ __forceinline__ F30 ld(int v) const {
+        asm volatile("" ::: "memory");   // a FRESH read every time: the point of parking is that the value is not kept live
+        uint32_t w[NL];
+        const uint32_t* q = quad + v * WORDS_PER_VALUE;
+        G16_UNROLL for (int g = 0; g < QUADS; ++g) {
+            const uint4 t = *reinterpret_cast<const uint4*>(q + g * 4 * ACC_THREADS);
+            w[4 * g] = t.x; w[4 * g + 1] = t.y; w[4 * g + 2] = t.z; w[4 * g + 3] = t.w;
+        }
+        const uint32_t* r = tail + v * WORDS_PER_VALUE;
+        G16_UNROLL for (int i = 0; i < TAIL; ++i) w[4 * QUADS + i] = r[i * ACC_THREADS];
+        return F30::from_limbs(w);
+    }
+    __device__ __forceinline__ void st(int v, const F30& a) const {
+        uint32_t w[NL];
+        a.get_limbs(w);
+        uint32_t* q = quad + v * WORDS_PER_VALUE;
+        G16_UNROLL for (int g = 0; g < QUADS; ++g)
+            *reinterpret_cast<uint4*>(q + g * 4 * ACC_THREADS) = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+        uint32_t* r = tail + v * WORDS_PER_VALUE;
+        G16_UNROLL for (int i = 0; i < TAIL; ++i) r[i * ACC_THREADS] = w[4 * QUADS + i];
+        asm volatile("" ::: "memory");
+    }
+};
+
 template <class F30, bool DIRECT>
 __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(
     const Affine<typename F30::Std>* __restrict__ bases, int64_t shift, uint64_t base_count, const uint32_t* __restrict__ sorted,
@@ -375,7 +410,21 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         if ((offsets[mid] >> off_shift) <= start) lo = mid; else hi = mid;
     }
     uint32_t b = lo, b_first = offsets[b] >> off_shift, b_end = offsets[b + 1] >> off_shift;
-    Acc30<F30> acc = Acc30<F30>::identity();
+    // F30::ACC_PARKED: the running sum's coordinates live in LDS (AccParked); otherwise in registers (Acc30)
+    __shared__ __attribute__((aligned(16))) uint32_t acc_lds[F30::ACC_PARKED ? 4 * F30::PREFIX_LIMBS * ACC_THREADS : 4];
+    typedef typename std::conditional<F30::ACC_PARKED, AccParked<F30, LdsAccStore<F30>>, Acc30<F30>>::type Acc;
+    Acc acc;
+    if constexpr (F30::ACC_PARKED) {
+        acc.s.quad = acc_lds + 4 * threadIdx.x;
+        acc.s.tail = acc_lds + 4 * LdsAccStore<F30>::QUADS * ACC_THREADS + threadIdx.x;
+        acc.inf = true;
+    } else {
+        acc = Acc30<F30>::identity();
+    }
+    auto flush = [&](AccRaw<typename F30::Raw>* dst) {
+        if constexpr (F30::ACC_PARKED) { acc.gather().store_raw(dst); acc.inf = true; }
+        else { acc.store_raw(dst); acc = Acc30<F30>::identity(); }
+    };
     // software pipeline: the base point of entry e+1 is gathered (and the sorted word of entry e+2 loaded) before the
     // ~20k-instruction addition of entry e, so the HBM latencies hide under arithmetic.  (Touching the cache lines of
     // entry e+2 with direct-to-LDS loads was tried for the window tables' wider gather: 25 % slower.)
@@ -400,8 +449,7 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
     uint32_t v_fetch = DIRECT ? start + 1 : (start + 1 < end ? sorted[start + 1] : 0u);   // entry e+1's word, loaded one iteration early
     for (uint32_t e = start; e < end; ++e) {
         if (e == b_end) {  // crossed into the next non-empty bucket: flush this segment's share of bucket b
-            acc.store_raw(&partials[slot_off[b] + (t - b_first / lseg)]);
-            acc = Acc30<F30>::identity();
+            flush(&partials[slot_off[b] + (t - b_first / lseg)]);
             do { ++b; b_end = offsets[b + 1] >> off_shift; } while (b_end <= e);
             b_first = offsets[b] >> off_shift;
         }
@@ -421,7 +469,7 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         }
         if constexpr (!F30::ACC_PREFETCH) advance();
     }
-    acc.store_raw(&partials[slot_off[b] + (t - b_first / lseg)]);
+    flush(&partials[slot_off[b] + (t - b_first / lseg)]);
 }
 
 // ---------------------------------------------------------------------------------------------

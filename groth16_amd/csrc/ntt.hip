@@ -64,11 +64,17 @@ __device__ __forceinline__ uint32_t lds_col(uint32_t e) { return e + (e >> 5); }
 
 // out[i] = scale * base^e(i),  e(i) = bitrev(i) if rev else i     (standard Montgomery arithmetic; `scale` may
 // carry the R'/R factor that turns the table into the w*R' form the 30-bit butterflies consume)
+// layered_log > 0: the per-stage twiddle layout of the NTT passes -- entry 2^s - 1 + k (k < 2^s, s < layered_log) holds
+// base^(k << (layered_log - 1 - s)), i.e. the 2^s twiddles of butterfly stage s CONTIGUOUSLY (n = 2^layered_log - 1 entries)
 template <class Fr>
-__global__ void gen_powers_kernel(Fr* __restrict__ out, size_t n, PowTable<Fr> tab, Fr scale, int rev_bits) {
+__global__ void gen_powers_kernel(Fr* __restrict__ out, size_t n, PowTable<Fr> tab, Fr scale, int rev_bits, int layered_log) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t e = rev_bits ? bitrev32((uint32_t)i, rev_bits) : (uint32_t)i;
+    if (layered_log > 0) {
+        const int s = 31 - __clz((uint32_t)i + 1u);
+        e = (((uint32_t)i + 1u) - (1u << s)) << (layered_log - 1 - s);
+    }
     Fr acc = scale;
     for (int j = 0; j < 32; ++j) {
         if ((e >> j) & 1) acc = acc * tab.p[j];
@@ -105,8 +111,10 @@ __device__ __forceinline__ void ntt30_round(uint32_t* lds, const Fp<P>* __restri
                 if (!((j >> q) & 1)) {
                     const int j2 = j | (1 << q);
                     // twiddle exponent = (global index of the lower element) mod 2^s, scaled to the n/2-entry table
-                    const uint64_t gi = gbase + ((uint64_t)j << (s_lo + q0));
-                    const uint64_t widx = (gi & ((1ull << s) - 1)) << (log_n - 1 - s);
+                    // (stage s's 2^s twiddles are contiguous in the layered table: lanes that walk consecutive low index bits read
+                    // consecutive 32-byte entries, where the flat n/2-entry table made every lane of a wave touch its own cache line)
+                    const uint32_t gi = (uint32_t)gbase + ((uint32_t)j << (s_lo + q0));
+                    const uint32_t widx = ((1u << s) - 1u) + (gi & ((1u << s) - 1u));
                     if (unit0 && s == 0) {   // uniform across the workgroup
                         const F u = x[j], v = x[j2];
                         x[j] = u.add(v);
@@ -440,13 +448,13 @@ int scale_by_table(typename C::Fr* data, const typename C::Fr* table, size_t n, 
 
 // table[i] = scale * base^e(i) * R'   (the form the 30-bit kernels multiply by)
 template <class Fr>
-static int gen_powers30(Fr* out, size_t n, const Fr& base, const Fr& scale, int rev_bits, hipStream_t st) {
+static int gen_powers30(Fr* out, size_t n, const Fr& base, const Fr& scale, int rev_bits, hipStream_t st, int layered_log = 0) {
     if (n == 0) return G16_OK;
     PowTable<Fr> tab;
     Fr p = base;
     for (int j = 0; j < 32; ++j) { tab.p[j] = p; p = p.sqr(); }
     const Fr scale30 = Fp30<typename Fr::Params>::std_to_r30(scale);
-    hipLaunchKernelGGL((gen_powers_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, tab, scale30, rev_bits);
+    hipLaunchKernelGGL((gen_powers_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, tab, scale30, rev_bits, layered_log);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
@@ -460,7 +468,7 @@ int gen_power_table(typename C::Fr* out, size_t n, const typename C::Fr& base, c
     PowTable<Fr> tab;
     Fr p = base;
     for (int j = 0; j < 32; ++j) { tab.p[j] = p; p = p.sqr(); }
-    hipLaunchKernelGGL((gen_powers_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, tab, scale, 0);
+    hipLaunchKernelGGL((gen_powers_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, tab, scale, 0, 0);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
@@ -472,7 +480,7 @@ int domain_create(int log_n, hipStream_t st, Domain<C>** out) {
     Domain<C>* d = new Domain<C>();
     d->log_n = log_n;
     d->n = (size_t)1 << log_n;
-    const size_t n = d->n, half = n / 2 ? n / 2 : 1;
+    const size_t n = d->n;
     Fr omega = C::two_adic_root();
     for (int i = log_n; i < C::TWO_ADICITY; ++i) omega = omega.sqr();
     Fr omega_inv = omega.inverse();
@@ -482,12 +490,13 @@ int domain_create(int log_n, hipStream_t st, Domain<C>** out) {
     d->zinv = (g.pow_u64((uint64_t)n) - Fr::one()).inverse();  // 1 / Z(g), r1cs_to_qap.rs:223-226 (standard form)
     int rc = G16_OK;
     auto fail = [&](int code) { domain_destroy<C>(d); return code; };
-    if (hipMalloc((void**)&d->tw_fwd, half * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
-    if (hipMalloc((void**)&d->tw_inv, half * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
+    const size_t ntw = n > 1 ? n - 1 : 1;   // layered: 2^s entries for every stage s < log_n
+    if (hipMalloc((void**)&d->tw_fwd, ntw * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
+    if (hipMalloc((void**)&d->tw_inv, ntw * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->s1_br, n * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->s2, n * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
-    if ((rc = gen_powers30<Fr>(d->tw_fwd, half, omega, Fr::one(), 0, st)) != G16_OK) return fail(rc);
-    if ((rc = gen_powers30<Fr>(d->tw_inv, half, omega_inv, Fr::one(), 0, st)) != G16_OK) return fail(rc);
+    if ((rc = gen_powers30<Fr>(d->tw_fwd, ntw, omega, Fr::one(), 0, st, log_n)) != G16_OK) return fail(rc);
+    if ((rc = gen_powers30<Fr>(d->tw_inv, ntw, omega_inv, Fr::one(), 0, st, log_n)) != G16_OK) return fail(rc);
     if ((rc = gen_powers30<Fr>(d->s1_br, n, g, n_inv, log_n, st)) != G16_OK) return fail(rc);
     if ((rc = gen_powers30<Fr>(d->s2, n, g_inv, n_inv, 0, st)) != G16_OK) return fail(rc);
     if (hipStreamSynchronize(st) != hipSuccess) return fail(G16_ERR_HIP);

@@ -506,6 +506,15 @@ class Groth16:
         lb = self._ctx.lib
         lb.check(lb.c.g16_prove_partial_prepare(self._ctx.handle, dpk.handle, dck.handle, C.c_void_p(z_dev_ptr), n_assign))
 
+    def prove_finalize_prepare(self, pk: ProvingKey, num_inputs: int, r: np.ndarray, s: np.ndarray, shard: Tuple[int, int],
+                               dist_h: bool = False):
+        """g16_prove_finalize_prepare: start the (r, s)-only half of the glue of prover.rs:76-131 on a host thread now, so that it
+        runs while the GPU computes this rank's partial sums; the next `finalize` over the same (key shard, r, s) picks it up"""
+        dpk = self._pk(pk, num_inputs, shard, dist_h=dist_h)
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_prove_finalize_prepare(self._ctx.handle, dpk.handle, ptr64(np.ascontiguousarray(r, dtype=np.uint64)),
+                                                 ptr64(np.ascontiguousarray(s, dtype=np.uint64))))
+
     def prove_partial_h(self, pk: ProvingKey, matrices: ConstraintMatrices, full_assignment, shard: Tuple[int, int],
                         h_dev_ptr: int, h_len: int, skip_b_g1: bool = False, z_dev_ptr: int = 0) -> bytes:
         """g16_prove_partial_h: the shard's five partial sums with h supplied by the caller (device memory: this rank's block of

@@ -26,7 +26,11 @@
  *                    ConstraintMatrices' Vec<Vec<(F, usize)>> rows
  * All functions return 0 on success or a g16_status; they never throw or unwind.
  * A g16_ctx is bound to one HIP device (g16_ctx_create) or to several (g16_ctx_create_multi) and is thread-compatible
- * (one call in flight per ctx).
+ * (one call in flight per ctx).  A g16_pk / g16_circuit may be used by every single-device context on the GPU it was loaded on
+ * (its device data is read-only during a proof; everything a proof writes belongs to the calling context), from different
+ * threads at once: two contexts on one GPU proving side by side over one key is the THROUGHPUT mode -- the head (witness map) and
+ * tail (reductions, host glue) of one proof run under the bucket passes of the other (bench.py reports it as `pipelined`).
+ * Free a key / circuit only when no call on any context is using it.
  */
 #ifndef G16_MI355X_H
 #define G16_MI355X_H
@@ -168,6 +172,13 @@ int g16_prove_partial(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit
                       uint64_t n_assign, int assignment_on_device, int skip_b_g1, g16_partial* out);
 int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts, int n_parts, const uint64_t r[4],
                        const uint64_t s[4], g16_proof* out);
+
+/* Optional, before (or while) the ranks' g16_prove_partial calls run: start on a host thread the half of the glue of
+ * src/prover.rs:76-131 that depends only on r, s and the key's fixed points -- r delta, s delta, r s delta and, by linearity of
+ * :94 and :114, s (r delta_g1 + a_query[0] + alpha_g1) and r (s delta_g1 + b_g1_query[0] + beta_g1).  The next g16_prove_finalize on
+ * this context over the same (pk, r, s) then only multiplies the two MSM sums by s and r, adds, and converts to affine; any other
+ * (pk, r, s) ignores the prepared half.  g16_prove does this by itself. */
+int g16_prove_finalize_prepare(g16_ctx* ctx, const g16_pk* pk, const uint64_t r[4], const uint64_t s[4]);
 
 /* ---- distributed witness map (the Amdahl term of the sharded proof) ----
  * h = witness_map_from_matrices (src/r1cs_to_qap.rs:172-235) over `world` ranks (a power of two <= 16 with world^2 | domain_size),

@@ -224,7 +224,8 @@ def pk_from_pymodel(cp, pk: "pymodel.ProvingKey") -> FlatPk:
 
 class Oracle:
     def __init__(self):
-        path = os.path.join(ROOT, "oracle", "libg16_oracle.so")
+        # G16_ORACLE_LIB: another build of the oracle (the sanitizer tier, tools/sanitize.sh, loads an ASan / UBSan build)
+        path = os.environ.get("G16_ORACLE_LIB", os.path.join(ROOT, "oracle", "libg16_oracle.so"))
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         self.lib = C.CDLL(path)

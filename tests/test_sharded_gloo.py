@@ -88,7 +88,14 @@ def _worker(rank, world, port, curve, q):
                            pk.h_query, pk.l_query)
         proof = g.finalize_host(curve, gpk, parts, r, s)
         want, _ = orc.prove(pk, ck, r, s)
-        q.put((rank, bool((proof.flat() == want).all()), rg))
+        ok = bool((proof.flat() == want).all())
+        # the glue is regrouped by linearity (the (r, s)-only half first, then s * sum_a and r * sum_b1): r = 0 (prover.rs:98-108: the
+        # reference skips B in G1; the records above still carry that MSM, which r = 0 must cancel), s = 0 and r = s = 0
+        z4 = np.zeros(4, dtype=np.uint64)
+        for rr, ss in ((z4, s), (r, z4), (z4, z4)):
+            want0, _ = orc.prove(pk, ck, rr, ss)
+            ok = ok and bool((g.finalize_host(curve, gpk, parts, rr, ss).flat() == want0).all())
+        q.put((rank, ok, rg))
     finally:
         dist.destroy_process_group()
 
