@@ -30,15 +30,19 @@ def pick(kernels, *subs):
     return hit
 
 
-@pytest.mark.parametrize("curve", ["Bls12_381FqP", "Bn254FqP"])
-def test_bucket_pass_keeps_two_waves_per_simd(kernels, curve):
-    # the production walk (sorted entry words) for G1 and the lane-pair G2 kernel
+@pytest.mark.parametrize("curve,limbs", [("Bls12_381FqP", 13), ("Bn254FqP", 9)])
+def test_bucket_pass_keeps_two_waves_per_simd_and_nothing_in_scratch(kernels, curve, limbs):
+    """the production walk (sorted entry words), G1 and the lane-pair G2 kernel.  Round 4: the accumulator's four coordinates live in
+    LDS (AccParked: 4 * NL words per lane, 64 lanes per workgroup) -- the G2 kernel, which spilled 392 B per lane into HBM-backed
+    scratch while using no LDS at all, and the G1 kernel must now have NO scratch, and keep two waves per SIMD (<= 256 registers)."""
     for field in ("Fp30<", "Fp2p30<"):
-        for name, k in pick(kernels, "bucket_accumulate30_kernel", field + curve, "false").items():
+        hit = pick(kernels, "bucket_accumulate30_kernel", field + curve, "false")
+        for name, k in hit.items():
             assert k["waves_per_simd"] >= 2, (name, k)
-    # G1: a handful of spilled dwords are tolerated (fused Y3), not a spilled working set
-    for name, k in pick(kernels, "bucket_accumulate30_kernel", "Fp30<" + curve, "false").items():
-        assert k["scratch"] <= 128, (name, k)
+            assert k["scratch"] == 0, (name, k)
+            assert k["lds"] == 4 * limbs * 64 * 4, (name, k)   # x, y, zz, zzz: NL words each for 64 lanes
+    # two waves per SIMD of eight single-wave workgroups per CU: their accumulator blocks must fit the CU's 160 KB of LDS
+    assert 8 * 4 * limbs * 64 * 4 <= 160 * 1024
 
 
 def test_ntt_kernels_keep_their_butterflies_in_registers(kernels):

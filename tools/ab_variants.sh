@@ -18,6 +18,6 @@ if not l:
     print(sys.argv[2], "BENCH FAILED |", sys.argv[3]); sys.exit()
 d = json.loads(l[-1]); p = d["phases_ms_per_step"]; r = d["roofline"]
 print(f"{sys.argv[2]:8s} proof {d['ms_per_step']:.2f} ms  G1 pass {r['avg_launch_ms']:.3f}  G2 pass {r['g2_bucket_avg_ms']:.3f}  ntt {p['ntt_ms']:.3f}  wm {p['witness_map_ms']:.3f}  "
-      f"finish {p['finish_ms']:.2f}  peak {r['valu_bound']['measured_peak_Tmad_s']:.2f} T/s  frac {r['valu_bound']['frac']:.3f} | proof {d.get('proof_sha256', '?')[:12]}")
+      f"pipelined {d.get('pipelined', {}).get('ms_per_proof', 0):.2f}  finish {p['finish_ms']:.2f}  peak {r['valu_bound']['measured_peak_Tmad_s']:.2f} T/s  frac {r['valu_bound']['frac']:.3f} | proof {d.get('proof_sha256', '?')[:12]}")
 PY
 done

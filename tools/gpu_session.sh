@@ -47,7 +47,7 @@ while [ $# -gt 0 ]; do
       name=bench$(echo "$args" | tr -d ' ' | tr -c 'a-zA-Z0-9\n' '_')
       timeout 900 python bench.py $args > $O/$name.json 2> $O/$name.err; echo "bench$args rc=$?"; last_json $O/$name.json ;;
     stats)
-      timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline \
+      timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined \
         > $O/bench_stats.json 2> $O/bench_stats.err; echo "stats rc=$?"
       find $O/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv; rm -rf $O/prof_stats
       head -12 $O/kernel_stats.csv ;;
@@ -57,7 +57,7 @@ while [ $# -gt 0 ]; do
       for c in FETCH_SIZE WRITE_SIZE; do
         mkdir -p $O/pmc_$c
         timeout 200 rocprofv3 --pmc $c -d $O/pmc_$c/calib -o pmc --output-format csv -- tools/bin/calib > $O/calib_$c.jsonl 2> $O/calib_$c.err
-        timeout 600 rocprofv3 --pmc $c -d $O/pmc_$c/bench -o pmc --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline \
+        timeout 600 rocprofv3 --pmc $c -d $O/pmc_$c/bench -o pmc --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined \
           > $O/bench_pmc_$c.json 2> $O/bench_pmc_$c.err
         echo "pmc $c rc=$?"
       done
@@ -76,7 +76,7 @@ PY
       ;;
     pmcsq)
       timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $O/pmc_sq -o pmc --output-format csv -- \
-        python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_pmc_sq.json 2> $O/bench_pmc_sq.err; echo "pmcsq rc=$?"
+        python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined > $O/bench_pmc_sq.json 2> $O/bench_pmc_sq.err; echo "pmcsq rc=$?"
       python - $O <<'PY'
 import json, subprocess, sys
 O = sys.argv[1]
@@ -100,7 +100,7 @@ PY
       find $O/prof_sim -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/sim8_k${k}_kernel_stats.csv; rm -rf $O/prof_sim ;;
     trace)   # per-kernel start / end timestamps of a few proofs (kernel trace only): tools/trace_timeline.py prints the timeline
       what=single; if [ $# -gt 0 ] && [[ "$1" == sim8 || "$1" == single ]]; then what=$1; shift; fi
-      if [ $what = sim8 ]; then cmd="python bench.py --sim-shards 8 --log2 22 --steps 3 --warmup 2"; else cmd="python bench.py --steps 2 --warmup 2 --no-cpu-baseline"; fi
+      if [ $what = sim8 ]; then cmd="python bench.py --sim-shards 8 --log2 22 --steps 3 --warmup 2"; else cmd="python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-pipelined"; fi
       timeout 600 rocprofv3 --kernel-trace -d $O/prof_trace_$what -o tr --output-format csv -- $cmd > $O/trace_$what.json 2> $O/trace_$what.err; echo "trace $what rc=$?"
       find $O/prof_trace_$what -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $O/kernel_trace_$what.csv; rm -rf $O/prof_trace_$what
       python tools/trace_timeline.py $O/kernel_trace_$what.csv | tail -120 ;;
