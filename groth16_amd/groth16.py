@@ -372,7 +372,8 @@ class Groth16:
         generate_constraints, matrices, full_assignment = instance ++ witness), then the pure-data call on the GPU.  The
         device copy of the matrices is cached, so proving the same circuit again uploads only the assignment: by
         `circuit_id` (any hashable the caller vouches for: same id = same constraint matrices; no hashing at all) or, without
-        one, by a SHA-1 of the matrices' content (bounded: the oldest entry and its device copy are dropped past 64 circuits)."""
+        one, by a SHA-1 of the matrices' content (bounded: the oldest entry and its device copy are dropped past 64 circuits --
+        which also invalidates any DistributedWitnessMap still holding that circuit's handle: create those after the circuits)."""
         import hashlib
 
         from .r1cs import synthesize
@@ -398,6 +399,16 @@ class Groth16:
                     ent[1].close()
             self._circuits_by_content[key] = m
         else:
+            if circuit_id is not None:
+                # the caller vouches that one id means one circuit; the cheap invariants are checked anyway -- a reused id would
+                # otherwise prove against the WRONG device matrices and hand back an invalid proof without any error
+                def shape(mm):
+                    return (mm.num_instance_variables, mm.num_witness_variables, mm.num_constraints,
+                            tuple(int(np.asarray(mat[0])[-1]) for mat in (mm.a, mm.b, mm.c)))   # row_ptr[-1] = nnz of A, B, C
+
+                if shape(known) != shape(m):
+                    raise ValueError(f"circuit_id {circuit_id!r} was first used for a circuit of shape {shape(known)} (instance, witness, "
+                                     f"constraints, nnz) and is now passed with one of shape {shape(m)}: one id must mean one circuit")
             m = known
         return self.create_proof_with_reduction_and_matrices(pk, r, s, m, cs.num_instance_variables, cs.num_constraints, cs.full_assignment())
 

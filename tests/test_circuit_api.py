@@ -146,6 +146,39 @@ def test_prove_and_verify_my_silly_circuit(curve):
         assert pm.verify_proof(cp, _vk(cp, vk), _proof(cp, zk), [63])
 
 
+class MySillyCircuitTwice(MySillyCircuit):
+    """another circuit over the same variables: twelve constraints instead of six"""
+
+    def generate_constraints(self, cs):
+        from groth16_amd import lc
+
+        a = cs.new_witness_variable(lambda: self.a)
+        b = cs.new_witness_variable(lambda: self.b)
+        c = cs.new_input_variable(lambda: None if self.a is None or self.b is None else self.a * self.b)
+        for _ in range(12):
+            cs.enforce_constraint(lc() + a, lc() + b, lc() + c)
+
+
+@pytest.mark.gpu
+def test_circuit_id_names_one_circuit():
+    """create_proof_with_reduction(..., circuit_id=...) skips hashing the matrices: the id IS the cache key.  The same id with another
+    circuit must be refused (it would prove against the cached, wrong device matrices and return an invalid proof silently);
+    the same id with the same circuit proves, uploads the matrices once, and verifies"""
+    import groth16_amd as g
+
+    cp = CP["bls12_381"]
+    rng = random.Random(5)
+    with g.Groth16("bls12_381", 0) as prover:
+        pk, vk = prover.setup(MySillyCircuit(), rng)
+        r, s = g.groth16._rand_fr("bls12_381", rng), g.groth16._rand_fr("bls12_381", rng)
+        for a, b in ((3, 5), (7, 11)):
+            proof = prover.create_proof_with_reduction(MySillyCircuit(a, b), pk, r, s, circuit_id="silly")
+            assert pm.verify_proof(cp, _vk(cp, vk), _proof(cp, proof), [a * b])
+        assert len(prover._cks) == 1
+        with pytest.raises(ValueError, match="one id must mean one circuit"):
+            prover.create_proof_with_reduction(MySillyCircuitTwice(3, 5), pk, r, s, circuit_id="silly")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 def test_rerandomize(curve):
