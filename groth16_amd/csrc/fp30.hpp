@@ -230,10 +230,11 @@ struct Fp30 {
     G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
     // a*b - c*d with ONE Montgomery reduction (the double-width sums share it): 3 NL^2 multiply-adds instead of 4 NL^2.
     // Requires d < 2p and a*b + 2p*c < ~400 p^2; output < 1.2p for the bounds the group formulas feed it.
-    // OPT-IN (G16_FP30_MUL_SUB).  Measured on the G1 bucket pass (Y3 = R (Q - X3) - Y1 PPP), same box each time: -4.7 % at
-    // equal occupancy, but the fused form needs ~15 more live registers than the 256 that keep two waves per SIMD; held to 256
-    // the allocator spills 18 dwords and the pass is 1.8 % SLOWER than two plain products in 252 registers (9.62 vs 9.45 ms,
-    // profiles/r02_ab_g1_occupancy.txt).  The bucket kernel therefore uses two products.
+    // In the REGISTER-RESIDENT accumulator (Acc30: reductions, table builder) this stays opt-in (G16_FP30_MUL_SUB): round 2 measured
+    // -4.7 % at equal occupancy, but the fused form needs ~15 more live registers than the 256 that keep two waves per SIMD; held
+    // to 256 the allocator spilled 18 dwords and the pass was 1.8 % SLOWER than two plain products (profiles/r02_ab_g1_occupancy.txt).
+    // The bucket pass itself no longer has that problem: its accumulator is parked in LDS (AccParked, round 4) and it calls
+    // mul_sub_fused below -- G1 pass 9.14 -> 8.90 ms (profiles/r04_ab_parked_accumulator.txt).
     G16_HD static Fp30 mul_sub(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) {
 #if defined(G16_FP30_OUTLINE) || !defined(G16_FP30_MUL_SUB)
         return a.mul(b).template sub<2>(c.mul(d));
@@ -643,9 +644,10 @@ struct Fp2p30 {
         B::template wide_relax<4>(T);
         return B::wide_redc(T);
     }
-    // Measured (profiles/r02_ab_mul_sub.txt, 2^22, same box): the fused form is 4.7 % FASTER for G1 (Fp30::mul_sub) but 5 %
-    // SLOWER here (27.9 -> 29.3 ms per G2 pass): eight operand sets + the column array exceed the 256 VGPRs the two-waves-per-SIMD
-    // bucket kernel has.  The lane-pair field therefore keeps two products (G16_PAIR_MUL_SUB opts in).
+    // Measured in round 2 (profiles/r02_ab_mul_sub.txt, 2^22, same box) inside the register-resident accumulator: the fused form was
+    // 4.7 % FASTER for G1 (Fp30::mul_sub) but 5 % SLOWER here (27.9 -> 29.3 ms per G2 pass): eight operand sets + the column array
+    // exceeded the 256 VGPRs of a two-waves-per-SIMD kernel.  Acc30 therefore keeps two products (G16_PAIR_MUL_SUB opts in); the bucket
+    // pass, whose accumulator sits in LDS since round 4, uses mul_sub_fused below.
     G16_HD static Fp2p30 mul_sub(const Fp2p30& a, const Fp2p30& b, const Fp2p30& c, const Fp2p30& d) {
 #ifdef G16_PAIR_MUL_SUB
         return {pair_mul_sub(lane_hi(), a.c, swap(a.c), b.c, swap(b.c), c.c, swap(c.c), d.c, swap(d.c))};

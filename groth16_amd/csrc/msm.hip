@@ -18,7 +18,8 @@
 //                           irrelevant because group addition commutes
 //   5. bucket_accumulate30_kernel  THE hot kernel: one lane (G1) / lane pair (G2) per 64-entry SEGMENT of the
 //                           sorted list gathers affine bases (96 B / 192 B each) and folds them with XYZZ
-//                           mixed additions (8M+2S, no inversion) in 30-bit lazy arithmetic (fp30.hpp),
+//                           mixed additions (8M+2S, no inversion; Y3 under one reduction) in 30-bit lazy arithmetic
+//                           (fp30.hpp), the running sum's four coordinates parked in LDS (AccParked, round 4),
 //                           flushing one partial sum per (bucket, segment) it touches
 //   5b. heavy_reduce_kernel cooperative combine of buckets with many partial sums
 //   6. bucket_reduce_kernel / window_reduce_kernel   sum_b (b+1) S_b by chunked running sums; chunk offsets through
@@ -36,8 +37,8 @@
 // of n*16 points (BLS12-381 and BN254 scalars); the 2^19 buckets are cut into 16 classes of 2^15 for the LDS histogram
 // (*_merged_kernel below), and the reductions treat a class like a window.  Costs 13x the key's memory (31 GB at 2^22
 // constraints on BLS12-381 -- HBM capacity is what this GPU has to spare) and a one-off table build at load time.
-// Roofline: step 5 reads ~N*W*(sizeof(Affine)+4) bytes (7.7 GB measured at 2^22, G1, merged windows) but spends ~10
-// field products (~3400 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
+// Roofline: step 5 reads ~N*W*(sizeof(Affine)+4) bytes (6.8 GB measured at 2^22, G1, merged windows) but spends ~10
+// field products (3 169 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
 // bytes/s it sustains is reported against the 8 TB/s roofline by bench.py regardless.
 #include "internal.hpp"
 #include "msm_common.hpp"
