@@ -991,6 +991,63 @@ struct AccParked {
     }
 };
 
+// The FULL addition (add-2008-s: XYZZ + XYZZ, 12 products + 2 squarings) with BOTH operands behind stores: d += s.  The reduction
+// kernels add partial sums that already live in memory (the bucket pass's flushed records, LDS tree nodes), so neither operand needs
+// to sit in registers as a whole -- a coordinate is fetched right before the product that consumes it.  Register-resident (Acc30::add)
+// the two operands alone are 8 coordinates = 104 registers per lane of a lane pair, and the G2 reduction kernels needed 496 registers:
+// ONE wave per SIMD, and no bucket-pass wave beside it.  Streamed, the live set is S1, R, PP, PPP, Q plus one operand.
+// d's store must support st(); s is read-only.  Same formulas, K constants and bounds as Acc30::add.  The exceptional cases (equal or
+// opposite points) take the register form -- cold.
+// dbl-2008-s-1 on a stored point, coordinates fetched where they are consumed (the cold branch of the streamed addition: kept as lean
+// as the hot path so that the kernels' register budget is not set by a branch that almost never runs)
+template <class F, class D>
+G16_HD void acc_dbl_streamed(D& d, bool& d_inf) {
+    enum { CX = 0, CY = 1, CZZ = 2, CZZZ = 3 };
+    if (d_inf) return;
+    const F U = d.ld(CY).dbl();
+    if (U.is_zero_exact()) { d_inf = true; return; }
+    const F V = U.sqr();
+    const F W = U.mul(V);
+    d.st(CZZ, V.mul(d.ld(CZZ)));
+    d.st(CZZZ, W.mul(d.ld(CZZZ)));
+    const F S = d.ld(CX).mul(V);
+    const F X2 = d.ld(CX).sqr();
+    const F M = X2.dbl().add(X2);
+    const F X3 = M.sqr().template sub<F::K2M>(S.dbl()).settle();
+    d.st(CX, X3);
+    d.st(CY, F::mul_sub(M, S.template sub<F::KX>(X3), d.ld(CY), W).settle());
+}
+
+template <class F, class D, class S>
+G16_HD void acc_add_streamed(D& d, bool& d_inf, const S& s, bool s_inf) {
+    enum { CX = 0, CY = 1, CZZ = 2, CZZZ = 3 };
+    if (s_inf) return;
+    if (d_inf) {
+        d.st(CX, s.ld(CX)); d.st(CY, s.ld(CY)); d.st(CZZ, s.ld(CZZ)); d.st(CZZZ, s.ld(CZZZ));
+        d_inf = false;
+        return;
+    }
+    const F U1 = d.ld(CX).mul(s.ld(CZZ));
+    const F S1 = d.ld(CY).mul(s.ld(CZZZ));
+    const F Pd = s.ld(CX).mul(d.ld(CZZ)).template sub<F::KM>(U1);
+    const F R = s.ld(CY).mul(d.ld(CZZZ)).template sub<F::KM>(S1);
+    if (Pd.maybe_zero()) {
+        if (Pd.is_zero_exact()) {
+            if (R.is_zero_exact()) acc_dbl_streamed<F>(d, d_inf);   // the same point: double it
+            else d_inf = true;
+            return;
+        }
+    }
+    const F PP = Pd.sqr();
+    d.st(CZZ, d.ld(CZZ).mul(s.ld(CZZ)).mul(PP));
+    const F PPP = Pd.mul(PP);
+    d.st(CZZZ, d.ld(CZZZ).mul(s.ld(CZZZ)).mul(PPP));
+    const F Q = U1.mul(PP);
+    const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
+    d.st(CX, X3);
+    d.st(CY, F::mul_sub(R, Q.template sub<F::KX>(X3), S1, PPP).settle());
+}
+
 // host-side Store for the self-tests: plain memory
 template <class F>
 struct ParkedArrayStore {

@@ -477,6 +477,19 @@ struct SelfTest {
         A a3 = A::identity();
         a3.set_double(B{1.0}, B{2.0});
         if (c.fail) { *report = c.fail; return 3; }
+        {   // the reductions' streamed addition / doubling on operands at those bounds, iterated like the chain above
+            ParkedArrayStore<B> ds, ss;
+            ds.v[0] = B{mx[0]}; ds.v[1] = B{mx[1]}; ds.v[2] = B{mx[2]}; ds.v[3] = B{mx[3]};
+            ss = ds;
+            bool dinf = false;
+            for (int it = 0; it < 50; ++it) {
+                acc_add_streamed<B>(ds, dinf, ss, false);
+                ss = ds;
+                bool sinf = false;
+                acc_dbl_streamed<B>(ss, sinf);
+            }
+            if (c.fail) { *report = c.fail; return 8; }
+        }
         // window-table builder: Jacobian doublings from an affine point
         B X{1.0}, Y{1.0}, Z{1.0};
         double jm[3] = {0, 0, 0};
@@ -604,6 +617,21 @@ struct SelfTest {
                 A30 sum = la; sum.add(lb);
                 G1X rs = a; rs.add(b);
                 if (!(sum.to_std().to_affine() == rs.to_affine())) return 40 + it;
+                {   // the reductions' streamed form of the same addition (both operands behind stores), and of the doubling
+                    ParkedArrayStore<F30> ds, ss;
+                    ds.v[0] = la.x; ds.v[1] = la.y; ds.v[2] = la.zz; ds.v[3] = la.zzz;
+                    ss.v[0] = lb.x; ss.v[1] = lb.y; ss.v[2] = lb.zz; ss.v[3] = lb.zzz;
+                    bool dinf = la.inf;
+                    acc_add_streamed<F30>(ds, dinf, ss, lb.inf);
+                    A30 got; got.inf = dinf; got.x = ds.v[0]; got.y = ds.v[1]; got.zz = ds.v[2]; got.zzz = ds.v[3];
+                    if (!(got.to_std().to_affine() == rs.to_affine())) return 5800 + it;
+                    ParkedArrayStore<F30> d2;
+                    d2.v[0] = la.x; d2.v[1] = la.y; d2.v[2] = la.zz; d2.v[3] = la.zzz;
+                    bool d2inf = la.inf;
+                    acc_dbl_streamed<F30>(d2, d2inf);
+                    A30 g2; g2.inf = d2inf; g2.x = d2.v[0]; g2.y = d2.v[1]; g2.zz = d2.v[2]; g2.zzz = d2.v[3];
+                    if (!(g2.to_std().to_affine() == a.dbl().to_affine())) return 5850 + it;
+                }
                 // storage round trip keeps the group element
                 if (!(A30::from_packed(sum.to_packed()).to_std().to_affine() == rs.to_affine())) return 60 + it;
                 A30 d = la; d.dbl();
@@ -718,6 +746,27 @@ struct SelfTest {
                 Acc30<F230> other = Acc30<F230>::from_packed(acc.to_packed());
                 G2X ro = ref;
                 other.dbl(); ro = ro.dbl();
+                {   // streamed forms on G2: (2 ref) + ref, ref + ref (the doubling branch), ref + (-ref)
+                    auto to_store = [](const Acc30<F230>& a) { ParkedArrayStore<F230> st; st.v[0] = a.x; st.v[1] = a.y; st.v[2] = a.zz; st.v[3] = a.zzz; return st; };
+                    auto from_store = [](const ParkedArrayStore<F230>& st, bool inf) { Acc30<F230> a; a.inf = inf; a.x = st.v[0]; a.y = st.v[1]; a.zz = st.v[2]; a.zzz = st.v[3]; return a; };
+                    ParkedArrayStore<F230> ds = to_store(other), ss = to_store(acc);
+                    bool dinf = other.inf;
+                    acc_add_streamed<F230>(ds, dinf, ss, acc.inf);
+                    G2X want3 = ro; want3.add(ref);
+                    if (!(from_store(ds, dinf).to_std().to_affine() == want3.to_affine())) return 5900 + round;
+                    ParkedArrayStore<F230> same = to_store(acc);
+                    bool sinf = acc.inf;
+                    acc_add_streamed<F230>(same, sinf, ss, acc.inf);
+                    if (!(from_store(same, sinf).to_std().to_affine() == ro.to_affine())) return 5910 + round;
+                    Acc30<F230> neg = acc;
+                    neg.y = neg.y.neg2();   // y < 3.5p here: neg2 needs < 2p -> go through the canonical form
+                    neg = Acc30<F230>::from_packed(acc.to_packed());
+                    neg.y = neg.y.neg2();
+                    ParkedArrayStore<F230> ns = to_store(neg), as = to_store(Acc30<F230>::from_packed(acc.to_packed()));
+                    bool ninf = false;
+                    acc_add_streamed<F230>(as, ninf, ns, false);
+                    if (!acc.inf && !ninf) return 5920 + round;
+                }
                 other.add(acc); ro.add(ref);
                 if (!(other.to_std().to_affine() == ro.to_affine())) return 2000 + round;
                 uint32_t kw[1] = {12345u + (uint32_t)round};

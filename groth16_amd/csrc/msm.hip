@@ -394,6 +394,62 @@ struct LdsAccStore {
     }
 };
 
+// The reduction kernels add with acc_add_streamed (fp30.hpp) for the fields whose limbs can be moved word by word (the same
+// fields whose bucket pass parks its accumulator); -DG16_REDUCE_STREAMED=0 rebuilds the register-resident form (A/B).
+#ifndef G16_REDUCE_STREAMED
+#define G16_REDUCE_STREAMED 1
+#endif
+template <class F30>
+static constexpr bool REDUCE_STREAMED = F30::ACC_PARKED && (G16_REDUCE_STREAMED != 0);
+
+// Stores for the reductions' streamed additions (acc_add_streamed, fp30.hpp).
+// An AccRaw record in LDS or global memory as the lane(s) of one task see it: coordinate k of a one-lane field is the k-th F30 of the
+// record; of the lane pair, component (lane parity) of the k-th Fq2.  Identity <=> zz is all-zero limbs (AccRaw).
+template <class F30>
+struct RawAccStore {
+    AccRaw<typename F30::Raw>* p;
+    __device__ __forceinline__ F30 ld(int k) const {
+        asm volatile("" ::: "memory");   // a fresh read where it is needed, not a value kept live from the top of the formula
+        if constexpr (F30::LANES_PER_TASK == 1) {
+            static_assert(sizeof(F30) == sizeof(typename F30::Raw), "one-lane fields share the raw layout");
+            return reinterpret_cast<const F30*>(p)[k];
+        } else {
+            typedef typename F30::B B30;
+            return F30{reinterpret_cast<const B30*>(p)[2 * k + (F30::lane_hi() ? 1 : 0)]};
+        }
+    }
+    __device__ __forceinline__ void st(int k, const F30& a) const {
+        if constexpr (F30::LANES_PER_TASK == 1) {
+            reinterpret_cast<F30*>(p)[k] = a;
+        } else {
+            typedef typename F30::B B30;
+            reinterpret_cast<B30*>(p)[2 * k + (F30::lane_hi() ? 1 : 0)] = a.c;
+        }
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ bool inf() const {
+        const F30 zz = ld(2);
+        if constexpr (F30::LANES_PER_TASK == 1) return zz.raw_zero();
+        else return F30::both(zz.c.raw_zero());
+    }
+    __device__ __forceinline__ void set_inf() const { st(2, F30::zero()); }
+};
+// four coordinates in registers (one-lane fields: the running sum of the bucket reduction)
+template <class F30>
+struct RegAccStore {
+    F30 v[4];
+    __device__ __forceinline__ F30 ld(int k) const { return v[k]; }
+    __device__ __forceinline__ void st(int k, const F30& a) { v[k] = a; }
+};
+template <class F30, class St>
+__device__ __forceinline__ Acc30<F30> gather_acc(const St& st, bool inf) {
+    Acc30<F30> a;
+    a.inf = inf;
+    if (inf) { a.x = a.y = a.zz = a.zzz = F30::zero(); return a; }
+    a.x = st.ld(0); a.y = st.ld(1); a.zz = st.ld(2); a.zzz = st.ld(3);
+    return a;
+}
+
 template <class F30, bool DIRECT>
 __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(
     const Affine<typename F30::Std>* __restrict__ bases, int64_t shift, uint64_t base_count, const uint32_t* __restrict__ sorted,
@@ -542,7 +598,7 @@ struct ReduceBatch {
 
 // (task = one lane, or one lane pair for the lane-pair Fq2: both lanes of a pair run the same control flow)
 template <class F30>
-__global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch) {
+__global__ __launch_bounds__(HEAVY_THREADS, REDUCE_STREAMED<F30> ? 2 : 1) void heavy_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
     constexpr uint32_t LPT = F30::LANES_PER_TASK, TASKS = HEAVY_THREADS / LPT;
@@ -553,6 +609,30 @@ __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(ReduceBatch
     for (uint32_t i = blockIdx.x; i < nheavy; i += gridDim.x) {
         const uint32_t b = heavy[1 + i];
         const uint32_t t0 = slot_off[b], t1 = slot_off[b + 1];
+        if constexpr (REDUCE_STREAMED<F30>) {
+            // streamed additions (acc_add_streamed): the task's sum lives in its LDS record from the start, every operand
+            // coordinate is fetched where it is consumed -- no 8-coordinate operand pair in registers
+            __syncthreads();  // previous iteration's readers are done with sh / partials[t0]
+            const RawAccStore<F30> mine{&sh[task]};
+            bool inf = true;
+            for (uint32_t q = t0 + task; q < t1; q += TASKS) {
+                const RawAccStore<F30> src{&partials[q]};
+                acc_add_streamed<F30>(mine, inf, src, src.inf());
+            }
+            if (inf) mine.set_inf();
+            __syncthreads();
+            for (uint32_t d = TASKS / 2; d > 0; d >>= 1) {
+                if (task < d) {
+                    const RawAccStore<F30> other{&sh[task + d]};
+                    bool mi = mine.inf();
+                    const bool was = mi;
+                    acc_add_streamed<F30>(mine, mi, other, other.inf());
+                    if (mi && !was) mine.set_inf();
+                }
+                __syncthreads();
+            }
+            if (task == 0) Acc30<F30>::load_raw(sh[0]).store_raw(&partials[t0]);
+        } else {
         Acc30<F30> acc = Acc30<F30>::identity();
         for (uint32_t q = t0 + task; q < t1; q += TASKS) acc.add(Acc30<F30>::load_raw(partials[q]));
         __syncthreads();  // previous iteration's readers are done with sh / partials[t0]
@@ -567,6 +647,7 @@ __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(ReduceBatch
             __syncthreads();
         }
         if (task == 0) Acc30<F30>::load_raw(sh[0]).store_raw(&partials[t0]);
+        }
     }
 }
 
@@ -574,7 +655,7 @@ __global__ __launch_bounds__(HEAVY_THREADS) void heavy_reduce_kernel(ReduceBatch
 // 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
 // ---------------------------------------------------------------------------------------------
 template <class F30>
-__global__ __launch_bounds__(RED_THREADS, F30::LANES_PER_TASK == 1 ? 2 : 1) void bucket_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t B, int W,
+__global__ __launch_bounds__(RED_THREADS, (F30::LANES_PER_TASK == 1 || REDUCE_STREAMED<F30>) ? 2 : 1) void bucket_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t B, int W,
                                                                     uint32_t G) {
     const AccRaw<typename F30::Raw>* __restrict__ partials = batch.partials[blockIdx.y];
     const uint32_t* __restrict__ slot_off = batch.slot_off[blockIdx.y];
@@ -584,6 +665,37 @@ __global__ __launch_bounds__(RED_THREADS, F30::LANES_PER_TASK == 1 ? 2 : 1) void
     const uint32_t t = (blockIdx.x * RED_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
     if (t >= cpw * (uint32_t)W) return;
     const uint32_t w = t / cpw, ch = t % cpw, b_lo = ch * G;
+    if constexpr (REDUCE_STREAMED<F30>) {
+        // two running sums, `run` (the buckets so far) and `tot` (the runs), added to with acc_add_streamed: the partial sums come
+        // straight from their records in memory, `tot` lives in LDS, and `run` in LDS too for the lane pair (for the one-lane field it
+        // stays in registers: 13 KB of LDS per workgroup keeps eight workgroups per CU for the batched G1 reduction of the tail)
+        constexpr bool PAIR = F30::LANES_PER_TASK == 2;
+        constexpr int SLOTS = PAIR ? 8 : 4;
+        __shared__ __attribute__((aligned(16))) uint32_t red_lds[SLOTS * F30::PREFIX_LIMBS * RED_THREADS];
+        static_assert(RED_THREADS == ACC_THREADS, "LdsAccStore is laid out for ACC_THREADS lanes");
+        LdsAccStore<F30> tot_s;
+        tot_s.quad = red_lds + 4 * threadIdx.x;
+        tot_s.tail = red_lds + 4 * LdsAccStore<F30>::QUADS * RED_THREADS + threadIdx.x;
+        typename std::conditional<PAIR, LdsAccStore<F30>, RegAccStore<F30>>::type run_s;
+        if constexpr (PAIR) {
+            run_s.quad = tot_s.quad + 4 * LdsAccStore<F30>::WORDS_PER_VALUE;
+            run_s.tail = tot_s.tail + 4 * LdsAccStore<F30>::WORDS_PER_VALUE;
+        }
+        bool run_inf = true, tot_inf = true;
+        for (uint32_t bb = G; bb-- > 0;) {
+            const uint32_t gb = w * B + b_lo + bb;
+            const uint32_t t0 = slot_off[gb];
+            uint32_t np = slot_off[gb + 1] - t0;
+            if (np > HEAVY_PARTS) np = 1;  // pre-combined into [t0] by heavy_reduce_kernel
+            for (uint32_t q = 0; q < np; ++q) {
+                const RawAccStore<F30> src{const_cast<AccRaw<typename F30::Raw>*>(&partials[t0 + q])};
+                acc_add_streamed<F30>(run_s, run_inf, src, src.inf());
+            }
+            acc_add_streamed<F30>(tot_s, tot_inf, run_s, run_inf);
+        }
+        gather_acc<F30>(run_s, run_inf).store_raw(&chunk_sum[t]);
+        gather_acc<F30>(tot_s, tot_inf).store_raw(&chunk_out[t]);
+    } else {
     Acc30<F30> run = Acc30<F30>::identity(), tot = Acc30<F30>::identity();
     for (uint32_t bb = G; bb-- > 0;) {
         const uint32_t gb = w * B + b_lo + bb;
@@ -597,12 +709,13 @@ __global__ __launch_bounds__(RED_THREADS, F30::LANES_PER_TASK == 1 ? 2 : 1) void
     // the chunks by the window level and the host (MsmPlan) -- no scalar multiplication in this chain of dependent additions
     run.store_raw(&chunk_sum[t]);
     tot.store_raw(&chunk_out[t]);
+    }
 }
 
 // grid = (groups, planes): plane 0 sums the chunks' weighted sums, plane 1 their plain sums, plane 2 + k the plain sums of the
 // chunks whose index has bit k set
 template <class F30>
-__global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t cpw) {
+__global__ __launch_bounds__(WIN_THREADS, REDUCE_STREAMED<F30> ? 2 : 1) void window_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t cpw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
     constexpr uint32_t LPT = F30::LANES_PER_TASK, TASKS = WIN_THREADS / LPT;
@@ -612,6 +725,27 @@ __global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(ReduceBatch<
     XYZZ<typename F30::Std>* __restrict__ window_sums = batch.window_sums[blockIdx.z];
     const AccRaw<typename F30::Raw>* src = (p == 0 ? chunk_out : chunk_sum) + (uint64_t)w * cpw;
     const uint32_t mask = p >= 2 ? 1u << (p - 2) : 0u;
+    if constexpr (REDUCE_STREAMED<F30>) {   // streamed additions, as in heavy_reduce_kernel
+        const RawAccStore<F30> mine{&sh[task]};
+        bool inf = true;
+        for (uint32_t j = task; j < cpw; j += TASKS)
+            if (!mask || (j & mask)) {
+                const RawAccStore<F30> s_j{const_cast<AccRaw<typename F30::Raw>*>(&src[j])};
+                acc_add_streamed<F30>(mine, inf, s_j, s_j.inf());
+            }
+        if (inf) mine.set_inf();
+        __syncthreads();
+        for (uint32_t d = TASKS / 2; d > 0; d >>= 1) {
+            if (task < d) {
+                const RawAccStore<F30> other{&sh[task + d]};
+                bool mi = mine.inf();
+                const bool was = mi;
+                acc_add_streamed<F30>(mine, mi, other, other.inf());
+                if (mi && !was) mine.set_inf();
+            }
+            __syncthreads();
+        }
+    } else {
     Acc30<F30> acc = Acc30<F30>::identity();
     for (uint32_t j = task; j < cpw; j += TASKS)
         if (!mask || (j & mask)) acc.add(Acc30<F30>::load_raw(src[j]));
@@ -624,6 +758,7 @@ __global__ __launch_bounds__(WIN_THREADS) void window_reduce_kernel(ReduceBatch<
             x.store_raw(&sh[task]);
         }
         __syncthreads();
+    }
     }
     // the plane sums are what leaves the device: standard arkworks Montgomery radix
     if (task == 0) Acc30<F30>::load_raw(sh[0]).store_std(&window_sums[(uint64_t)w * gridDim.y + p]);

@@ -67,10 +67,12 @@ def test_window_table_builders_have_no_per_lane_arrays(kernels):
         assert k["waves_per_simd"] >= 2, (name, k)
 
 
-def test_batched_g1_reduction_keeps_two_waves_per_simd(kernels):
-    """the four G1 reductions run as one throughput-bound launch per stage (msm_reduce_batch): at one wave per SIMD (the batch
-    parameter block once pushed bucket_reduce_kernel to 320 registers) they would take twice as long"""
+def test_reductions_keep_two_waves_per_simd_and_nothing_in_scratch(kernels):
+    """the three reduction kernels, G1 and lane-pair G2.  Round 3: the G2 ones needed 376 + 120 registers (ONE wave per SIMD, and no
+    bucket-pass wave beside them) and bucket_reduce_kernel<Fp30> spilled 144 B.  Round 4: they add with acc_add_streamed (both operands
+    behind stores, coordinates fetched where they are consumed): every one of the six must fit two waves per SIMD with no scratch."""
     for sub in ("bucket_reduce_kernel<", "window_reduce_kernel<", "heavy_reduce_kernel<"):
-        for name, k in pick(kernels, sub, "Fp30<").items():
-            assert k["waves_per_simd"] >= 2, (name, k)
-            assert k["scratch"] <= 192, (name, k)
+        for field in ("Fp30<", "Fp2p30<"):
+            for name, k in pick(kernels, sub, field).items():
+                assert k["waves_per_simd"] >= 2, (name, k)
+                assert k["scratch"] == 0, (name, k)
