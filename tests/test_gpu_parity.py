@@ -460,7 +460,7 @@ def test_bench_two_ranks_one_gpu(launcher):
     c4 = d2["configs4"]
     assert "error" not in c4, c4
     assert c4["log2_domain"] == 13 and c4["n_gpus"] == 2 and c4["ranks_agree_on_proof"] and c4["value"] > 0
-    out13 = subprocess.run(base1 + ["--log2", "13"], env=env, capture_output=True, text=True, timeout=600)
+    out13 = subprocess.run(base1 + ["--log2", "13", "--key", "synthetic"], env=env, capture_output=True, text=True, timeout=600)   # the leg's key
     assert out13.returncode == 0, out13.stderr[-2000:]
     d13 = json.loads([l for l in out13.stdout.splitlines() if l.startswith("{")][-1])
     assert c4["proof_sha256"] == d13["proof_sha256"]
