@@ -83,7 +83,7 @@ struct Domain {
     size_t n = 0;
     // twiddles, layered per butterfly stage: entry 2^s - 1 + k = w^(k * n / 2^(s+1)), k < 2^s, s < log_n  (n - 1 entries;
     // stage s's twiddles are contiguous, so the lanes of a wave read consecutive entries instead of one cache line each)
-    Fr* tw_fwd = nullptr;
+    Fr* tw_fwd = nullptr;    // (entries in the butterflies' own form: ntt.hip `Tw` -- the 30-bit limbs, not packed words)
     Fr* tw_inv = nullptr;    // the same over w^-1
     Fr* s1_br = nullptr;     // n^-1 * g^bitrev(i)   (between inverse-DIF and coset-DIT)
     Fr* s2 = nullptr;        // n^-1 * g^-k          (after the final inverse-DIF, natural index)

@@ -59,6 +59,37 @@ static constexpr int NTT_ROW = NTT_TILE + NTT_TILE / 32;  // padded row length (
 template <class Fr>
 struct PowTable { Fr p[32]; };  // base^(2^j)
 
+// One twiddle as the butterflies consume it.  G16_NTT_TW_UNPACKED = 1: the NL 30-bit limbs themselves (9 words for the 255-bit scalar
+// fields instead of the 8 packed ones) -- no shift / mask / align work per butterfly; 0: the packed w*R' words of rounds 1-3.
+#ifndef G16_NTT_TW_UNPACKED
+#define G16_NTT_TW_UNPACKED 1
+#endif
+template <class P>
+struct Tw { uint32_t w[G16_NTT_TW_UNPACKED ? Fp30<P>::NL : P::N]; };
+template <class P>
+__device__ __forceinline__ Fp30<P> load_tw(const Tw<P>& e) {
+#if G16_NTT_TW_UNPACKED
+    Fp30<P> r;
+    G16_UNROLL for (int i = 0; i < Fp30<P>::NL; ++i) r.l[i] = e.w[i];
+    return r;
+#else
+    return Fp30<P>::unpack(e.w);
+#endif
+}
+template <class P>
+__global__ void tw_convert_kernel(const Fp<P>* __restrict__ in, Tw<P>* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Tw<P> e;
+#if G16_NTT_TW_UNPACKED
+    const Fp30<P> x = Fp30<P>::unpack(in[i].v);
+    G16_UNROLL for (int k = 0; k < Fp30<P>::NL; ++k) e.w[k] = x.l[k];
+#else
+    G16_UNROLL for (int k = 0; k < P::N; ++k) e.w[k] = in[i].v[k];
+#endif
+    out[i] = e;
+}
+
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 __device__ __forceinline__ uint32_t lds_col(uint32_t e) { return e + (e >> 5); }
 
@@ -88,7 +119,7 @@ __global__ void gen_powers_kernel(Fr* __restrict__ out, size_t n, PowTable<Fr> t
 // inputs are reduced (< 2p: canonical data or a pre-scale product); DIF: the difference stays lazy (< 2^(kdone + 2) p), which
 // the canonicalising / pre-scale product that always follows a DIF stage 0 absorbs.
 template <class P, bool DIT, int R, class GIdx>
-__device__ __forceinline__ void ntt30_round(uint32_t* lds, const Fp<P>* __restrict__ tw, int log_n, int s_lo, int q0, int TT, uint32_t E,
+__device__ __forceinline__ void ntt30_round(uint32_t* lds, const Tw<P>* __restrict__ tw, int log_n, int s_lo, int q0, int TT, uint32_t E,
                                             int done, const GIdx& gidx, bool unit0) {
     typedef Fp30<P> F;
     constexpr int NL = F::NL;
@@ -121,7 +152,7 @@ __device__ __forceinline__ void ntt30_round(uint32_t* lds, const Fp<P>* __restri
                         x[j2] = DIT ? u.template sub<2>(v) : u.sub_pow2(v, kdone);
                         continue;
                     }
-                    const F w = F::unpack(tw[widx].v);
+                    const F w = load_tw<P>(tw[widx]);
                     if (DIT) {
                         const F v = x[j2].mul_impl(w);           // < 1.01 p
                         const F u = x[j];
@@ -150,7 +181,7 @@ template <class P>
 struct NttBatch { Fp<P>* p[3]; };
 
 template <class P, bool DIT>
-__global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_pass_kernel(NttBatch<P> batch, const Fp<P>* __restrict__ tw,
+__global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_pass_kernel(NttBatch<P> batch, const Tw<P>* __restrict__ tw,
                                                                  const Fp<P>* __restrict__ prescale, int log_n, int s_lo, int s_hi,
                                                                  int T) {
     typedef Fp30<P> F;
@@ -220,8 +251,8 @@ __global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_pass_ker
 // less per DIF/DIT pair (three pairs per witness map).  `prescale` is applied between the two (x lazy, < 2^K p: fine for
 // the product).
 template <class P>
-__global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_dif_dit_kernel(NttBatch<P> batch, const Fp<P>* __restrict__ tw_dif,
-                                                                    const Fp<P>* __restrict__ tw_dit, const Fp<P>* __restrict__ prescale,
+__global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_dif_dit_kernel(NttBatch<P> batch, const Tw<P>* __restrict__ tw_dif,
+                                                                    const Tw<P>* __restrict__ tw_dit, const Fp<P>* __restrict__ prescale,
                                                                     int log_n, int K) {
     typedef Fp30<P> F;
     constexpr int NL = F::NL;
@@ -329,7 +360,7 @@ static std::vector<PassPlan> plan_passes(int log_n) {
 }
 
 template <class P, bool DIT>
-static int launch_pass(const NttBatch<P>& batch, int nbatch, const Fp<P>* tw, const Fp<P>* prescale, int log_n, const PassPlan& pp, hipStream_t st) {
+static int launch_pass(const NttBatch<P>& batch, int nbatch, const Tw<P>* tw, const Fp<P>* prescale, int log_n, const PassPlan& pp, hipStream_t st) {
     const int K = pp.s_hi - pp.s_lo;
     const int TT = pp.s_lo == 0 ? 0 : pp.T;
     const size_t E = (size_t)1 << (K + TT);
@@ -361,7 +392,7 @@ int ntt_dif_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, b
     if (nbatch < 1 || nbatch > 3) return G16_ERR_INTERNAL;
     if (d->log_n == 0) return G16_OK;
     auto passes = plan_passes(d->log_n);
-    const typename C::Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
+    const Tw<P>* tw = reinterpret_cast<const Tw<P>*>(inverse ? d->tw_inv : d->tw_fwd);
     const NttBatch<P> b = make_batch<C>(data, nbatch);
     for (size_t i = passes.size(); i-- > 0;) G16_TRY((launch_pass<P, false>(b, nbatch, tw, nullptr, d->log_n, passes[i], st)));
     return G16_OK;
@@ -378,7 +409,7 @@ int ntt_dit_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, b
         return G16_OK;
     }
     auto passes = plan_passes(d->log_n);
-    const typename C::Fr* tw = inverse ? d->tw_inv : d->tw_fwd;
+    const Tw<P>* tw = reinterpret_cast<const Tw<P>*>(inverse ? d->tw_inv : d->tw_fwd);
     const NttBatch<P> b = make_batch<C>(data, nbatch);
     for (size_t i = 0; i < passes.size(); ++i)
         G16_TRY((launch_pass<P, true>(b, nbatch, tw, i == 0 ? prescale : nullptr, d->log_n, passes[i], st)));
@@ -399,8 +430,8 @@ int ntt_dif_dit_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatc
         return G16_OK;
     }
     auto passes = plan_passes(d->log_n);
-    const typename C::Fr* tw1 = dif_inverse ? d->tw_inv : d->tw_fwd;
-    const typename C::Fr* tw2 = dif_inverse ? d->tw_fwd : d->tw_inv;
+    const Tw<P>* tw1 = reinterpret_cast<const Tw<P>*>(dif_inverse ? d->tw_inv : d->tw_fwd);
+    const Tw<P>* tw2 = reinterpret_cast<const Tw<P>*>(dif_inverse ? d->tw_fwd : d->tw_inv);
     const NttBatch<P> b = make_batch<C>(data, nbatch);
     for (size_t i = passes.size(); i-- > 1;) G16_TRY((launch_pass<P, false>(b, nbatch, tw1, nullptr, d->log_n, passes[i], st)));
     {
@@ -491,15 +522,24 @@ int domain_create(int log_n, hipStream_t st, Domain<C>** out) {
     int rc = G16_OK;
     auto fail = [&](int code) { domain_destroy<C>(d); return code; };
     const size_t ntw = n > 1 ? n - 1 : 1;   // layered: 2^s entries for every stage s < log_n
-    if (hipMalloc((void**)&d->tw_fwd, ntw * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
-    if (hipMalloc((void**)&d->tw_inv, ntw * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
+    typedef Tw<typename Fr::Params> TwE;
+    Fr* tw_tmp = nullptr;   // the generator writes packed words; the tables hold the butterflies' own form (Tw)
+    if (hipMalloc((void**)&d->tw_fwd, ntw * sizeof(TwE)) != hipSuccess) return fail(G16_ERR_OOM);
+    if (hipMalloc((void**)&d->tw_inv, ntw * sizeof(TwE)) != hipSuccess) return fail(G16_ERR_OOM);
+    if (hipMalloc((void**)&tw_tmp, ntw * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->s1_br, n * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->s2, n * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
-    if ((rc = gen_powers30<Fr>(d->tw_fwd, ntw, omega, Fr::one(), 0, st, log_n)) != G16_OK) return fail(rc);
-    if ((rc = gen_powers30<Fr>(d->tw_inv, ntw, omega_inv, Fr::one(), 0, st, log_n)) != G16_OK) return fail(rc);
+    for (int dir = 0; dir < 2; ++dir) {
+        if ((rc = gen_powers30<Fr>(tw_tmp, ntw, dir ? omega_inv : omega, Fr::one(), 0, st, log_n)) != G16_OK) { (void)hipFree(tw_tmp); return fail(rc); }
+        hipLaunchKernelGGL((tw_convert_kernel<typename Fr::Params>), dim3((unsigned)((ntw + 255) / 256)), dim3(256), 0, st, tw_tmp,
+                           reinterpret_cast<TwE*>(dir ? d->tw_inv : d->tw_fwd), ntw);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(tw_tmp); return fail(G16_ERR_HIP); }
+    }
     if ((rc = gen_powers30<Fr>(d->s1_br, n, g, n_inv, log_n, st)) != G16_OK) return fail(rc);
     if ((rc = gen_powers30<Fr>(d->s2, n, g_inv, n_inv, 0, st)) != G16_OK) return fail(rc);
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(G16_ERR_HIP);
+    const bool sync_ok = hipStreamSynchronize(st) == hipSuccess;
+    (void)hipFree(tw_tmp);
+    if (!sync_ok) return fail(G16_ERR_HIP);
     *out = d;
     return G16_OK;
 }
