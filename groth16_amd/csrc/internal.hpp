@@ -127,6 +127,8 @@ struct DeviceCircuit {
     Domain<C>* dom = nullptr;
 };
 // d_z: full assignment on device; d_h: n Fr out (natural order).  Scratch comes from the arena.
+// after the CSR upload: flag the unit coefficients in the DEVICE column indices (bit 31), see witness_map.hip
+template <class C> int mark_unit_coefficients(DeviceCircuit<C>* ck, hipStream_t st);
 template <class C> int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, typename C::Fr* d_h, Arena& arena,
                                           hipStream_t st, EventTimer* ntt_timers = nullptr);
 

@@ -236,7 +236,9 @@ struct KeyLoader {
                     return fail(G16_ERR_HIP);
             }
         }
-        int rc = domain_create<C>(log_n, ctx->stream, &dc->dom);
+        int rc = mark_unit_coefficients<C>(dc, ctx->stream);
+        if (rc) return fail(rc);
+        rc = domain_create<C>(log_n, ctx->stream, &dc->dom);
         if (rc) return fail(rc);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(G16_ERR_HIP);
         g16_circuit* h = new (std::nothrow) g16_circuit{C::CURVE_ID, ctx, dc, (uint64_t)1 << log_n};

@@ -39,9 +39,14 @@ __global__ void spmv3_kernel(SpmvArgs<Fr> args, const Fr* __restrict__ z, uint64
         const uint64_t b = args.row_ptr[m][row], e = args.row_ptr[m][row + 1];
         const Fr one = Fr::one();
         for (uint64_t k = b; k < e; ++k) {
-            const Fr coeff = args.val[m][k];
-            const Fr v = z[args.col[m][k]];
-            acc = acc + ((coeff == one) ? v : v * coeff);  // coeff.is_one() fast path, r1cs_to_qap.rs:37,57
+            const uint32_t c = args.col[m][k];
+            if (c >> 31) {   // marked at load time (mark_unit_coefficients): the coefficient is one -- its 32 bytes are not even read
+                acc = acc + z[c & 0x7fffffffu];                     // coeff.is_one() fast path, r1cs_to_qap.rs:37,57
+            } else {
+                const Fr coeff = args.val[m][k];
+                const Fr v = z[c];
+                acc = acc + ((coeff == one) ? v : v * coeff);
+            }
         }
     } else if (m == 0 && row - nc < num_inputs) {
         acc = z[row - nc];
@@ -271,6 +276,27 @@ int dwm_stage(const DeviceCircuit<C>* ck, const DistWm<C>* d, int stage, const t
                               typename C::Fr* const[3], typename C::Fr*, hipStream_t);
 G16_INSTANTIATE_DWM(Bls12_381)
 G16_INSTANTIATE_DWM(Bn254)
+
+// Circuit load: bit 31 of a device column index says "this coefficient is 1" (R1CS matrices are mostly +-1), so the sparse mat-vec
+// skips the 32-byte coefficient read for those entries.  Only when every index fits 31 bits; the caller's arrays are not touched.
+template <class Fr>
+__global__ void mark_unit_kernel(uint32_t* __restrict__ col, const Fr* __restrict__ val, uint64_t nnz) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz && val[k] == Fr::one()) col[k] |= 0x80000000u;
+}
+template <class C>
+int mark_unit_coefficients(DeviceCircuit<C>* ck, hipStream_t st) {
+    if (ck->num_variables >= (1ull << 31)) return G16_OK;
+    for (int m = 0; m < 3; ++m) {
+        if (!ck->nnz[m]) continue;
+        hipLaunchKernelGGL((mark_unit_kernel<typename C::Fr>), dim3((unsigned)((ck->nnz[m] + 255) / 256)), dim3(256), 0, st, ck->col[m], ck->val[m],
+                           ck->nnz[m]);
+        G16_LAUNCH_CHECK();
+    }
+    return G16_OK;
+}
+template int mark_unit_coefficients<Bls12_381>(DeviceCircuit<Bls12_381>*, hipStream_t);
+template int mark_unit_coefficients<Bn254>(DeviceCircuit<Bn254>*, hipStream_t);
 
 template int witness_map_device<Bls12_381>(const DeviceCircuit<Bls12_381>*, const Bls12_381::Fr*, Bls12_381::Fr*, Arena&, hipStream_t, EventTimer*);
 template int witness_map_device<Bn254>(const DeviceCircuit<Bn254>*, const Bn254::Fr*, Bn254::Fr*, Arena&, hipStream_t, EventTimer*);
