@@ -627,7 +627,9 @@ def main():
             roofline_ntt = dict(bound="hbm", achieved=ntt_bytes / (ntt_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, kernel="ntt30_* (7 radix-2 transforms of size n per proof)",
                                 ms_per_step=ntt_ms, algorithmic_bytes_per_step=ntt_bytes, traffic=ntt_traffic,
-                                note="Fr-product bound in practice (DESIGN.md 4.2); replicated on every rank when sharded")
+                                note="instruction-bound in practice (DESIGN.md 4.2); ms_per_step includes the pointwise quotient "
+                                     "(a b - c) / Z, fused into the first sweep of the seventh transform since round 4 (it used to be a "
+                                     "0.18 ms kernel outside this timer); replicated on every rank when sharded")
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload; not measured in this run)" if traffic else None,
                         traffic_calibration=traffic_cal,

@@ -97,6 +97,9 @@ template <class C> int domain_ensure_gpow(Domain<C>* d, hipStream_t st);
 // in-place passes over n = 2^log_n elements on device
 // natural -> bit-reversed (Gentleman-Sande), roots = d->tw_inv if inverse else d->tw_fwd, no scaling
 template <class C> int ntt_dif(const Domain<C>* d, typename C::Fr* data, bool inverse, hipStream_t st);
+// the same transform of q = (a .* b - c) * zinv (in place in a), the pointwise quotient fused into the first sweep's load
+template <class C> int ntt_dif_quotient(const Domain<C>* d, typename C::Fr* a, const typename C::Fr* b, const typename C::Fr* c,
+                                        const typename C::Fr& zinv, bool inverse, hipStream_t st);
 // bit-reversed -> natural (Cooley-Tukey); each input element is first multiplied by prescale[i] if non-null
 template <class C> int ntt_dit(const Domain<C>* d, typename C::Fr* data, bool inverse, const typename C::Fr* prescale, hipStream_t st);
 // ntt_dif(inverse = dif_inverse) then ntt_dit(inverse = !dif_inverse, prescale); the two innermost passes share one kernel

@@ -179,11 +179,16 @@ __device__ __forceinline__ void ntt30_round(uint32_t* lds, const Tw<P>* __restri
 // of the distributed map only 256); three chains per launch fill the chip and cut the launches of the six transforms to a third.
 template <class P>
 struct NttBatch { Fp<P>* p[3]; };
+// Optional fused input of a pass (b != nullptr): the element is (data * b - c) * zinv instead of data -- the pointwise quotient
+// (a b - c) / Z(g) of r1cs_to_qap.rs:223-230 computed where the first sweep of the last transform reads it, instead of a kernel of
+// its own that writes q for this sweep to read back (standard Montgomery products, as that kernel used).
+template <class P>
+struct NttQuot { const Fp<P>* b; const Fp<P>* c; Fp<P> zinv; };
 
 template <class P, bool DIT>
 __global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_pass_kernel(NttBatch<P> batch, const Tw<P>* __restrict__ tw,
                                                                  const Fp<P>* __restrict__ prescale, int log_n, int s_lo, int s_hi,
-                                                                 int T) {
+                                                                 int T, NttQuot<P> quot) {
     typedef Fp30<P> F;
     constexpr int NL = F::NL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -220,7 +225,13 @@ __global__ __launch_bounds__(NTT_THREADS, G16_NTT_MIN_WAVES) void ntt30_pass_ker
     // ---- load the tile (coalesced 32-byte elements), optional pre-scale
     for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
         const uint64_t g = gidx(e);
-        F x = F::unpack(data[g].v);
+        F x;
+        if (quot.b) {
+            const Fp<P> t = (data[g] * quot.b[g] - quot.c[g]) * quot.zinv;
+            x = F::unpack(t.v);
+        } else {
+            x = F::unpack(data[g].v);
+        }
         if (prescale) x = x.mul_impl(F::unpack(prescale[g].v));
         lds_store(e, x);
     }
@@ -360,7 +371,8 @@ static std::vector<PassPlan> plan_passes(int log_n) {
 }
 
 template <class P, bool DIT>
-static int launch_pass(const NttBatch<P>& batch, int nbatch, const Tw<P>* tw, const Fp<P>* prescale, int log_n, const PassPlan& pp, hipStream_t st) {
+static int launch_pass(const NttBatch<P>& batch, int nbatch, const Tw<P>* tw, const Fp<P>* prescale, int log_n, const PassPlan& pp, hipStream_t st,
+                       const NttQuot<P>* quot = nullptr) {
     const int K = pp.s_hi - pp.s_lo;
     const int TT = pp.s_lo == 0 ? 0 : pp.T;
     const size_t E = (size_t)1 << (K + TT);
@@ -373,8 +385,11 @@ static int launch_pass(const NttBatch<P>& batch, int nbatch, const Tw<P>* tw, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
+    NttQuot<P> q;
+    if (quot) q = *quot;
+    else { q.b = nullptr; q.c = nullptr; q.zinv = Fp<P>::zero(); }
     hipLaunchKernelGGL((ntt30_pass_kernel<P, DIT>), dim3((unsigned)blocks, (unsigned)nbatch), dim3(NTT_THREADS), lds_bytes, st, batch, tw, prescale,
-                       log_n, pp.s_lo, pp.s_hi, pp.T);
+                       log_n, pp.s_lo, pp.s_hi, pp.T, q);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
@@ -399,6 +414,23 @@ int ntt_dif_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, b
 }
 template <class C>
 int ntt_dif(const Domain<C>* d, typename C::Fr* data, bool inverse, hipStream_t st) { return ntt_dif_batch<C>(d, &data, 1, inverse, st); }
+
+// ntt_dif of q = (a .* b - c) * zinv, in place in `a`, with the pointwise quotient fused into the load of the first sweep
+template <class C>
+int ntt_dif_quotient(const Domain<C>* d, typename C::Fr* a, const typename C::Fr* b, const typename C::Fr* c, const typename C::Fr& zinv,
+                     bool inverse, hipStream_t st) {
+    typedef typename C::Fr::Params P;
+    auto passes = plan_passes(d->log_n);
+    const Tw<P>* tw = reinterpret_cast<const Tw<P>*>(inverse ? d->tw_inv : d->tw_fwd);
+    typename C::Fr* data[1] = {a};
+    const NttBatch<P> batch = make_batch<C>(data, 1);
+    NttQuot<P> q;
+    q.b = b; q.c = c; q.zinv = zinv;
+    if (d->log_n == 0) return G16_ERR_INTERNAL;   // (a one-point domain has no pass to fuse into; the caller keeps the plain kernel)
+    for (size_t i = passes.size(); i-- > 0;)
+        G16_TRY((launch_pass<P, false>(batch, 1, tw, nullptr, d->log_n, passes[i], st, i + 1 == passes.size() ? &q : nullptr)));
+    return G16_OK;
+}
 
 template <class C>
 int ntt_dit_batch(const Domain<C>* d, typename C::Fr* const* data, int nbatch, bool inverse, const typename C::Fr* prescale, hipStream_t st) {
@@ -564,6 +596,7 @@ void domain_destroy(Domain<C>* d) {
     template void domain_destroy<C>(Domain<C>*);                                                                   \
     template int domain_ensure_gpow<C>(Domain<C>*, hipStream_t);                                                   \
     template int ntt_dif<C>(const Domain<C>*, typename C::Fr*, bool, hipStream_t);                                 \
+    template int ntt_dif_quotient<C>(const Domain<C>*, typename C::Fr*, const typename C::Fr*, const typename C::Fr*, const typename C::Fr&, bool, hipStream_t); \
     template int ntt_dit<C>(const Domain<C>*, typename C::Fr*, bool, const typename C::Fr*, hipStream_t);          \
     template int ntt_dif_dit<C>(const Domain<C>*, typename C::Fr*, bool, const typename C::Fr*, hipStream_t);      \
     template int ntt_dif_batch<C>(const Domain<C>*, typename C::Fr* const*, int, bool, hipStream_t);              \

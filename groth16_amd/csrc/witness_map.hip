@@ -89,10 +89,20 @@ int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, ty
     // chains in one launch per sweep
     G16_TRY((ntt_dif_dit_batch<C>(dom, outs, 3, /*dif_inverse=*/true, dom->s1_br, st)));
     if (ntt_timers) G16_TRY(ntt_timers[0].stop(st));
+    if (ntt_timers) G16_TRY(ntt_timers[1].start(st));
+#ifdef G16_NO_FUSED_QUOTIENT
     hipLaunchKernelGGL((quotient_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, c, dom->zinv, n);
     G16_LAUNCH_CHECK();
-    if (ntt_timers) G16_TRY(ntt_timers[1].start(st));
     G16_TRY((ntt_dif<C>(dom, a, /*inverse=*/true, st)));
+#else
+    // (a b - c) / Z(g) (r1cs_to_qap.rs:223-230) is computed by the first sweep of the last transform as it loads its tile
+    if (dom->log_n == 0) {
+        hipLaunchKernelGGL((quotient_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, c, dom->zinv, n);
+        G16_LAUNCH_CHECK();
+    } else {
+        G16_TRY((ntt_dif_quotient<C>(dom, a, b, c, dom->zinv, /*inverse=*/true, st)));
+    }
+#endif
     G16_TRY((bitrev_scale<C>(dom, d_h, a, dom->s2, nullptr, st)));
     if (ntt_timers) G16_TRY(ntt_timers[1].stop(st));
     return G16_OK;
