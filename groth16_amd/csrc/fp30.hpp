@@ -79,9 +79,16 @@ struct Fp30 {
     G16_HD Fp30 sub(const Fp30& b) const {
         Fp30 r;
         G16_UNROLL for (int i = 0; i < NL; ++i) {
-            const uint32_t kp = K == 2 ? P::kp2(i) : K == 4 ? P::kp4(i) : K == 8 ? P::kp8(i) : P::kp16(i);
+            const uint32_t kp = K == 2 ? P::kp2(i) : K == 4 ? P::kp4(i) : K == 6 ? P::kp6(i) : K == 8 ? P::kp8(i) : P::kp16(i);
             r.l[i] = l[i] + kp - b.l[i];
         }
+        r.normalize();
+        return r;
+    }
+    // a + 2 b with ONE normalisation (limbs < 3 * 2^30 before it)      bound: A + 2 B
+    G16_HD Fp30 add_dbl(const Fp30& b) const {
+        Fp30 r;
+        G16_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = l[i] + (b.l[i] << 1);
         r.normalize();
         return r;
     }
@@ -308,7 +315,10 @@ struct Fp30 {
 #define G16_ACC_MIN_WAVES 2
 #endif
     static constexpr int ACC_MIN_WAVES = G16_ACC_MIN_WAVES;
-    static constexpr bool ACC_PREFETCH = true;
+#ifndef G16_G1_PREFETCH
+#define G16_G1_PREFETCH true
+#endif
+    static constexpr bool ACC_PREFETCH = G16_G1_PREFETCH;
 #ifndef G16_G1_PARKED
 #define G16_G1_PARKED 1
 #endif
@@ -434,6 +444,7 @@ struct Fp2x30 {
     G16_HD static Fp2x30 from_packed(const Std& x) { return {B::unpack(x.c0.v), B::unpack(x.c1.v)}; }
     G16_HD Fp2x30 add(const Fp2x30& o) const { return {c0.add(o.c0), c1.add(o.c1)}; }
     G16_HD Fp2x30 dbl() const { return {c0.dbl(), c1.dbl()}; }
+    G16_HD Fp2x30 add_dbl(const Fp2x30& o) const { return {c0.add_dbl(o.c0), c1.add_dbl(o.c1)}; }
     template <int K>
     G16_HD Fp2x30 sub(const Fp2x30& o) const { return {c0.template sub<K>(o.c0), c1.template sub<K>(o.c1)}; }
     G16_HD Fp2x30 neg2() const { return {c0.neg2(), c1.neg2()}; }
@@ -515,6 +526,7 @@ struct Fp2k30 {
     G16_HD static Fp2k30 from_packed(const Std& x) { return {B::unpack(x.c0.v), B::unpack(x.c1.v)}; }
     G16_HD Fp2k30 add(const Fp2k30& o) const { return {c0.add(o.c0), c1.add(o.c1)}; }
     G16_HD Fp2k30 dbl() const { return {c0.dbl(), c1.dbl()}; }
+    G16_HD Fp2k30 add_dbl(const Fp2k30& o) const { return {c0.add_dbl(o.c0), c1.add_dbl(o.c1)}; }
     template <int K>
     G16_HD Fp2k30 sub(const Fp2k30& o) const { return {c0.template sub<K>(o.c0), c1.template sub<K>(o.c1)}; }
     G16_HD Fp2k30 neg2() const { return {c0.neg2(), c1.neg2()}; }
@@ -668,6 +680,7 @@ struct Fp2p30 {
     G16_HD static Fp2p30 one() { return {lane_hi() ? B::zero() : B::one()}; }
     G16_HD Fp2p30 add(const Fp2p30& o) const { return {c.add(o.c)}; }
     G16_HD Fp2p30 dbl() const { return {c.dbl()}; }
+    G16_HD Fp2p30 add_dbl(const Fp2p30& o) const { return {c.add_dbl(o.c)}; }
     template <int K>
     G16_HD Fp2p30 sub(const Fp2p30& o) const { return {c.template sub<K>(o.c)}; }
     G16_HD Fp2p30 neg2() const { return {c.neg2()}; }
@@ -985,7 +998,13 @@ struct AccParked {
         const F PPP = Pd.mul(PP);
         s.st(CZZZ, s.ld(CZZZ).mul(PPP));
         const F Q = s.ld(CX).mul(PP);
+        // X3 = R^2 - (PPP + 2 Q): the subtrahend is formed with one normalisation and subtracted once (K = KM + K2M: the same bound
+        // as two subtractions) -- two normalisation sweeps and a doubling less than R^2 - PPP - 2Q taken term by term
+#ifdef G16_NO_FUSED_X3
         const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
+#else
+        const F X3 = R.sqr().template sub<F::KM + F::K2M>(PPP.add_dbl(Q)).settle();
+#endif
         s.st(CX, X3);
         s.st(CY, F::mul_sub_fused(R, Q.template sub<F::KX>(X3), s.ld(CY), PPP).settle());
     }
@@ -1043,7 +1062,7 @@ G16_HD void acc_add_streamed(D& d, bool& d_inf, const S& s, bool s_inf) {
     const F PPP = Pd.mul(PP);
     d.st(CZZZ, d.ld(CZZZ).mul(s.ld(CZZZ)).mul(PPP));
     const F Q = U1.mul(PP);
-    const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
+    const F X3 = R.sqr().template sub<F::KM + F::K2M>(PPP.add_dbl(Q)).settle();
     d.st(CX, X3);
     d.st(CY, F::mul_sub(R, Q.template sub<F::KX>(X3), S1, PPP).settle());
 }

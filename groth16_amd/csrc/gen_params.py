@@ -76,7 +76,7 @@ def field_struct(name, p):
     out.append("    static constexpr uint32_t PINV30 = 0x%08xu;   // -p^-1 mod 2^30" % ((-pow(p, -1, 1 << 30)) % (1 << 30)))
     out.append("    static constexpr uint32_t PPINV30 = 0x%08xu;  //  p^-1 mod 2^30" % (pow(p, -1, 1 << 30)))
     for fn, vals in (("p30", limbs30(p)), ("one30", limbs30(R30 % p)), ("rstd30", limbs30(R % p)), ("r3_30", limbs30(pow(R30, 3, p))), ("kp2", redundant(2)),
-                     ("kp4", redundant(4)), ("kp8", redundant(8)), ("kp16", redundant(16)), ("np2", limbs30(2 * p)),
+                     ("kp4", redundant(4)), ("kp6", redundant(6)), ("kp8", redundant(8)), ("kp16", redundant(16)), ("np2", limbs30(2 * p)),
                      ("np4", limbs30(4 * p)), ("np8", limbs30(8 * p)), ("np16", limbs30(16 * p))):
         out.append("    G16_HD static constexpr uint32_t %s(int i) {" % fn)
         out.append("        constexpr uint32_t t[NL30] = %s;" % arr(vals))

@@ -58,6 +58,7 @@ struct BoundF {
     static BoundF one() { return {1.0}; }
     BoundF add(const BoundF& o) const { return {b + o.b}; }
     BoundF dbl() const { return {2.0 * b}; }
+    BoundF add_dbl(const BoundF& o) const { return {b + 2.0 * o.b}; }
     template <int K> BoundF sub(const BoundF& o) const { check(o.b <= K - 1e-3, "sub<K>: subtrahend not below K p"); return {b + K}; }
     BoundF neg2() const { check(b <= 2.0 - 1e-3 || b == 1.0, "neg2: operand not below 2p"); return {2.0}; }
     static BoundF product(double A, double B, double T) {
