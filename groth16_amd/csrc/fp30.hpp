@@ -118,13 +118,16 @@ struct Fp30 {
     // ---- double-width column primitives (T has 2*NL 64-bit columns) -----------------------------
     // One sweep of limb products adds CNT(c) = min(c + 1, 2 NL - 1 - c) products (each < 2^60) to column c.  A 64-bit column
     // holds 15 of them plus the small carries that travel with it, so sweeps can pile up in a column WITHOUT any carry work
-    // until (sweeps so far + 1) * CNT(c) would pass 15; only then is the column "relaxed" (wide_relax), and only that column:
-    // for NL = 13 that is 11 of 25 columns between a product and its reduction, none at all for NL <= 7.
+    // until (sweeps so far + 1) * CNT(c) would pass G16_RELAX_LIMIT; only then is the column "relaxed" (wide_relax), and only that
+    // column: for NL = 13 that is 9 of 25 columns between a product and its reduction, none at all for NL <= 8.
     // The column type is a template parameter so that the host self-test can run every routine with 128-bit columns beside the
     // 64-bit ones on all-ones limbs and demand identical results (no overflow anywhere).
 #ifndef G16_RELAX_LIMIT
-#define G16_RELAX_LIMIT 15   // products (< 2^60 each) a 64-bit column holds with room for the carries (the 128-bit shadow self-test on
-                             // all-ones limbs still passes at 17 and fails at 20)
+#define G16_RELAX_LIMIT 16   // products (< 2^60 each) a 64-bit column may hold before it is relaxed.  16 (2^30 - 1)^2 = 2^64 - 2^35 + 16 leaves
+                             // 2^35 - 16 for the carries that travel with a column (a relaxation carry < 2^34, the reduction's carry < 2^34);
+                             // g16_host_selftest PROVES the plan for the real moduli by worst-case bound propagation (hosttest.hip
+                             // column_headroom: codes 605-609; 16 and 17 give the same plan, 18 fails with 605) beside the 128-bit shadow
+                             // runs.  Rounds 2-3 used 15: 11 relaxed columns per 13-limb product instead of 9.
 #endif
     static constexpr int col_count(int c) { return c + 1 < 2 * NL - 1 - c ? c + 1 : 2 * NL - 1 - c; }
     // T = a*b as NL^2 limb products

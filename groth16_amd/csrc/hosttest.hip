@@ -221,9 +221,58 @@ struct SelfTest {
     // Column-overflow check of the carry-free product routines (fp30.hpp: wide_mul / wide_relax / wide_redc): every routine is
     // run twice, with 64-bit and with 128-bit columns, on the worst limbs the representation allows (all 2^30 - 1) and on
     // random limbs.  The 128-bit run cannot overflow; identical limbs out mean the 64-bit run did not either.
+    // WORST CASE over all inputs of every 64-bit column of the lazy product forms, by bound propagation through the very plan the
+    // kernels are generated from (col_count, G16_RELAX_LIMIT): operand limbs at most 2^30 - 1, every reduction multiplier m_i at most
+    // 2^30 - 1, the field's REAL modulus limbs.  (The all-ones-limbs shadow runs below exercise one m sequence; this covers them all.)
+    // sweeps = operand sweeps in front of the reduction: 1 (mul, sqr), 2 (lane-pair product, a b - c d), 4 (lane-pair a b - c d).
+    template <class R30>
+    static int column_headroom() {
+        typedef unsigned __int128 W;
+        constexpr int NL = R30::NL;
+        const W M = R30::MASK, LIM = (W)1 << 64;
+        const int forms[3] = {1, 2, 4};
+        for (int f = 0; f < 3; ++f) {
+            const int sweeps = forms[f];
+            W T[2 * NL];
+            for (int c = 0; c < 2 * NL; ++c) T[c] = 0;
+            for (int s = 1; s <= sweeps; ++s) {
+                for (int c = 0; c < 2 * NL - 1; ++c) {
+                    T[c] += (W)R30::col_count(c) * M * M;
+                    if (T[c] >= LIM) return 605;
+                }
+                for (int c = 0; c + 1 < 2 * NL; ++c)     // wide_relax<s>
+                    if ((s + 1) * R30::col_count(c) > G16_RELAX_LIMIT) {
+                        T[c + 1] += (T[c] >> 32) << 2;
+                        if (T[c + 1] >= LIM) return 606;
+                        if (T[c] > 0xffffffffu) T[c] = 0xffffffffu;
+                    }
+            }
+            W carry = 0;
+            for (int i = 0; i < NL; ++i) {                // wide_redc
+                T[i] += carry;
+                if (T[i] >= LIM) return 607;
+                for (int j = 0; j < NL; ++j) {
+                    T[i + j] += M * (W)R30::Params_t::p30(j);
+                    if (T[i + j] >= LIM) return 608;
+                }
+                carry = T[i] >> 30;
+            }
+            for (int j = 0; j < NL; ++j) {
+                const W v = T[NL + j] + carry;
+                if (v >= LIM) return 609;
+                carry = v >> 30;
+            }
+        }
+        return 0;
+    }
+
     template <class R30>
     static int selftest_columns(uint64_t seed, int iters) {
         typedef unsigned __int128 U128;
+        {
+            const int rc = column_headroom<R30>();
+            if (rc) return rc;
+        }
         uint64_t st = seed ^ 0xC0;
         for (int it = 0; it < iters + 4; ++it) {
             R30 a, b, c, d;
