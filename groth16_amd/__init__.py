@@ -17,12 +17,12 @@ Reference interface mirrored (paths relative to /root/reference):
       synthesis (groth16_amd.r1cs: ConstraintSystem, Variable, lc, ConstraintSynthesizer) in front of the GPU calls
 """
 from .binding import (G16Error, Lib, PolynomialDegreeTooLarge, SynthesisError, UnexpectedIdentity, lib, FQ_LIMBS, CURVE_ID)  # noqa: F401
-from .groth16 import (ConstraintMatrices, Groth16, LibsnarkReduction, Proof, ProvingKey, ShardedProver, finalize_host,  # noqa: F401
+from .groth16 import (ConstraintMatrices, Groth16, LibsnarkReduction, PipelinedProver, Proof, ProvingKey, ShardedProver, finalize_host,  # noqa: F401
                       rerandomize_proof, shard_ranges)
 from .r1cs import AssignmentMissing, ConstraintSynthesizer, ConstraintSystem, LinearCombination, Variable, lc  # noqa: F401
 
 __all__ = [
-    "Groth16", "LibsnarkReduction", "ConstraintMatrices", "ProvingKey", "Proof", "ShardedProver", "G16Error", "SynthesisError",
+    "Groth16", "LibsnarkReduction", "ConstraintMatrices", "ProvingKey", "Proof", "ShardedProver", "PipelinedProver", "G16Error", "SynthesisError",
     "PolynomialDegreeTooLarge", "UnexpectedIdentity", "lib", "ConstraintSystem", "ConstraintSynthesizer", "Variable", "LinearCombination",
     "lc", "AssignmentMissing",
 ]

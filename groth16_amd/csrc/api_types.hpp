@@ -199,6 +199,9 @@ struct DevicePk {
     mutable FixedBaseTable<typename C::G2X> delta2_tab;
     mutable std::mutex tab_mu;
     mutable int finalize_calls = 0;
+    // set (release) only AFTER both tables are complete; readers that are not inside tab_mu look at this flag (acquire), never at the
+    // tables' own emptiness: a key may serve two contexts at once, and a reader must not walk a table another thread is still filling
+    mutable std::atomic<bool> tabs_ready{false};
 };
 
 struct g16_pk {

@@ -116,12 +116,17 @@ struct ProofGlue {
     }
     static void ensure_delta_tables(const DevicePk<C>* pk) {   // built on the second proof over a key (32 * 256 additions each)
         std::lock_guard<std::mutex> lk(pk->tab_mu);
-        if (!pk->delta2_tab.ready() && ++pk->finalize_calls >= 2) {
+        if (!pk->tabs_ready.load(std::memory_order_relaxed) && ++pk->finalize_calls >= 2) {
             auto f1 = std::async(std::launch::async, [&]() { pk->delta1_tab.build(G1X::from_affine(pk->delta_g1)); });
             pk->delta2_tab.build(G2X::from_affine(pk->delta_g2));
             f1.get();
+            pk->tabs_ready.store(true, std::memory_order_release);
         }
     }
+    // the tables, or nullptr while they do not exist / are being built by another context's thread (the glue then multiplies delta
+    // bit by bit: correct, 0.5 ms slower, first proofs over a key only)
+    static const FixedBaseTable<G1X>* table1(const DevicePk<C>* pk) { return pk->tabs_ready.load(std::memory_order_acquire) ? &pk->delta1_tab : nullptr; }
+    static const FixedBaseTable<G2X>* table2(const DevicePk<C>* pk) { return pk->tabs_ready.load(std::memory_order_acquire) ? &pk->delta2_tab : nullptr; }
     // start the prepared half on a host thread; g16_prove_finalize over the same (key, r, s) picks it up
     static int prove_finalize_prepare(g16_ctx* ctx, const g16_pk* pkh, const uint64_t* r_, const uint64_t* s_) {
         const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
@@ -135,7 +140,7 @@ struct ProofGlue {
         const uint64_t* ss = ctx->finprep.s;
         ctx->finprep.fut = std::async(std::launch::async, [pk, data, rr, ss]() {
             ensure_delta_tables(pk);
-            *data = finalize_prepare_core(fixed_points(pk), rr, ss, &pk->delta1_tab, &pk->delta2_tab);
+            *data = finalize_prepare_core(fixed_points(pk), rr, ss, table1(pk), table2(pk));
         });
         ctx->finprep.valid = true;
         return G16_OK;
@@ -152,7 +157,7 @@ struct ProofGlue {
             G16_TRY(finalize_finish(*static_cast<const FinalizePrep*>(keep.get()), parts, n_parts, out));
         } else {
             ensure_delta_tables(pk);
-            G16_TRY(finalize_core(fixed_points(pk), parts, n_parts, r_, s_, out, &pk->delta1_tab, &pk->delta2_tab));
+            G16_TRY(finalize_core(fixed_points(pk), parts, n_parts, r_, s_, out, table1(pk), table2(pk)));
         }
         const double dt = now_ms() - t0;
         ctx->tm.finish_ms += dt;

@@ -219,6 +219,40 @@ def test_proof_valid_crs_and_trapdoor(env, orc, g, k):
     assert (nozk.flat() == orc.prove(pk, ck, z4, z4)[0]).all()
 
 
+def test_pipelined_prover_two_contexts_one_key(env, orc, g):
+    """throughput mode: two contexts on the one GPU over ONE device-resident key and circuit (a g16_pk / g16_circuit may serve every
+    single-device context of its GPU), two worker threads, proofs in flight side by side -- every proof must equal the oracle's, the
+    key and the circuit must have been loaded once, and the plain C call with a key owned by ANOTHER context must work as well"""
+    import ctypes as C
+
+    from groth16_amd.binding import ProofC, ptr64
+
+    curve, prover = env
+    ck = orc.syn_circuit(curve, 11, 2)
+    pk, _ = orc.setup(ck, 9)
+    gm, gp = mats_of(g, ck), pk_of(g, pk)
+    rs = [(orc.rand_fr(curve, 300 + i, 1)[0], orc.rand_fr(curve, 400 + i, 1)[0]) for i in range(8)]
+    rs[3] = (np.zeros(4, dtype=np.uint64), rs[3][1])     # r == 0 among them
+    with g.PipelinedProver(curve, 0) as pp:
+        futs = [pp.submit(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z) for r, s in rs]
+        proofs = [f.result(timeout=300) for f in futs]
+        assert len(pp._owner._pks) == 1 and len(pp._owner._cks) == 1 and not pp._second._pks and not pp._second._cks
+        # the C ABI directly: the existing fixture context proves with the PipelinedProver's key and circuit handles
+        dpk, dck = pp._owner._pk(gp, ck.num_inputs), pp._owner._ck(gm)
+        out = ProofC()
+        lb = prover._ctx.lib
+        z = np.ascontiguousarray(ck.z)
+        lb.check(lb.c.g16_prove(prover._ctx.handle, dpk.handle, dck.handle, z.ctypes.data, z.shape[0], 0, ptr64(rs[0][0]), ptr64(rs[0][1]),
+                                C.byref(out)))
+        L = len(proofs[0].a) // 2
+        direct = np.concatenate([np.array(out.a[: 2 * L], dtype=np.uint64), np.array(out.b[: 4 * L], dtype=np.uint64),
+                                 np.array(out.c[: 2 * L], dtype=np.uint64)])
+    for (r, s), proof in zip(rs, proofs):
+        want, _ = orc.prove(pk, ck, r, s)
+        assert (proof.flat() == want).all()
+    assert (direct == orc.prove(pk, ck, *rs[0])[0]).all()
+
+
 def test_proof_valid_crs_2_16_trapdoor_and_pairing(env, orc, g):
     """a VALID proving key at 2^16 constraints (oracle setup, a few seconds): the GPU proof equals the closed form
     computed from the trapdoor (scalar arithmetic and three fixed-base multiplications, no MSM) and passes the pairing verifier"""
