@@ -256,7 +256,9 @@ void g16_pk_free(g16_pk* pk) {
         delete pk;
         return;
     }
-    if (pk->ctx->finprep.pk == pk) pk->ctx->finprep.drop();   // a prepared finalize half may still be reading the key's fixed points
+    // a prepared finalize half of this key on its own context is forgotten here; halves prepared by OTHER contexts that share the
+    // key hold their own reference to its host side (KeyGlue) and are matched by key id, so they neither dangle nor match a later key
+    if (pk->ctx->finprep.key_id == pk->id) pk->ctx->finprep.drop();
     (void)hipSetDevice(pk->ctx->device);
     if (pk->curve == G16_BLS12_381) Impl<Bls12_381>::pk_free(static_cast<DevicePk<Bls12_381>*>(pk->dp));
     else Impl<Bn254>::pk_free(static_cast<DevicePk<Bn254>*>(pk->dp));
@@ -345,6 +347,7 @@ int g16_prove_finalize(g16_ctx* ctx, const g16_pk* pk, const g16_partial* parts,
         if (pk->subs.empty()) return G16_ERR_BAD_ARG;
         return g16_prove_finalize(ctx->subs[0], pk->subs[0], parts, n_parts, r, s, out);
     }
+    if (!pk->subs.empty() || !pk->dp) return G16_ERR_BAD_ARG;   // a multi-device key on a single-device context
     G16_DISPATCH(ctx->curve, I::prove_finalize(ctx, pk, parts, n_parts, r, s, out));
 }
 
@@ -355,6 +358,7 @@ int g16_prove_finalize_prepare(g16_ctx* ctx, const g16_pk* pk, const uint64_t r[
         if (pk->subs.empty()) return G16_ERR_BAD_ARG;
         return g16_prove_finalize_prepare(ctx->subs[0], pk->subs[0], r, s);
     }
+    if (!pk->subs.empty() || !pk->dp) return G16_ERR_BAD_ARG;   // a multi-device key on a single-device context
     G16_DISPATCH(ctx->curve, I::prove_finalize_prepare(ctx, pk, r, s));
 }
 
@@ -380,6 +384,7 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
         if (!pk->subs.empty()) (void)g16_prove_finalize_prepare(ctx->subs[0], pk->subs[0], r, s);   // host glue under the GPU work
         if (pk->dist_n && (circuit->dist.empty() || pk->dist_n != circuit->domain_size)) {
             g_last_error = "the key's h_query does not belong to this circuit's domain (h_query must hold domain_size - 1 bases)";
+            ctx->subs[0]->finprep.drop();
             return G16_ERR_BAD_LENGTH;
         }
         int rc;
@@ -391,7 +396,7 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
             // events, the next stage (which overwrites work[]) on the pullers' pull events; the host barriers only make sure an
             // event has been recorded before somebody waits on it.  Then the MSMs: the witness sort and the four h-independent
             // passes start at once, the h MSM follows the map (g16_prove_partial_h orders itself after the witness-map stream).
-            if (n_assign != circuit->num_variables) return G16_ERR_BAD_LENGTH;
+            if (n_assign != circuit->num_variables) { ctx->subs[0]->finprep.drop(); return G16_ERR_BAD_LENGTH; }
             HostBarrier bar(n);
             std::atomic<int> failed{0};
             const uint64_t M = circuit->domain_size / (uint64_t)n, blk = M / (uint64_t)n;
@@ -477,7 +482,7 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                                          assignment_on_device, skip_b_g1, &parts[(size_t)i]);
             });
         }
-        if (rc) return rc;
+        if (rc) { ctx->subs[0]->finprep.drop(); return rc; }
         rc = g16_prove_finalize(ctx->subs[0], pk->subs[0], parts.data(), n, r, s, out);
         // timings: the slowest device's phases (the proof waits for it), wall time of the whole call
         int slow = 0;
@@ -488,7 +493,11 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
         ctx->tm.total_ms = now_ms() - t0;
         return rc;
     }
-    if (!ctx || !pk) return G16_ERR_BAD_ARG;
+    // (the argument checks of g16_prove_partial, made BEFORE a host thread is started on the key)
+    if (!ctx || !pk || !circuit || !full_assignment) return G16_ERR_BAD_ARG;
+    if (pk->curve != ctx->curve || circuit->curve != ctx->curve || !pk->subs.empty() || !pk->dp || !circuit->subs.empty() || !circuit->dc)
+        return G16_ERR_BAD_ARG;
+    if (!usable_on(pk->ctx, ctx) || !usable_on(circuit->ctx, ctx)) return G16_ERR_BAD_ARG;
     int rc = g16_prove_finalize_prepare(ctx, pk, r, s);   // the (r, s)-only host glue runs while the GPU works
     if (rc) return rc;
     rc = g16_prove_partial(ctx, pk, circuit, full_assignment, n_assign, assignment_on_device, skip_b_g1, &part);

@@ -125,16 +125,16 @@ struct g16_ctx {
         bool valid = false;
         std::future<void> fut;
         std::shared_ptr<void> data;
-        const g16_pk* pk = nullptr;
+        uint64_t key_id = 0;   // g16_pk::id of the key it was prepared for (ids are never reused, addresses are)
         uint64_t r[4] = {}, s[4] = {};
-        bool matches(const g16_pk* p, const uint64_t* r_, const uint64_t* s_) const {
-            return valid && pk == p && memcmp(r, r_, 32) == 0 && memcmp(s, s_, 32) == 0;
+        bool matches(uint64_t id, const uint64_t* r_, const uint64_t* s_) const {
+            return valid && key_id == id && memcmp(r, r_, 32) == 0 && memcmp(s, s_, 32) == 0;
         }
-        void drop() {   // wait for a running thread (it reads the key) and forget its result
-            if (valid && fut.valid()) fut.wait();
+        void drop() {   // wait for a running thread and forget its result (the thread holds its own reference to the key's host half)
+            if (fut.valid()) fut.wait();
             valid = false;
             data.reset();
-            pk = nullptr;
+            key_id = 0;
         }
     } finprep;
     void* pinned = nullptr;  // window sums land here (hipHostMalloc)
@@ -179,12 +179,31 @@ struct g16_circuit {
     uint64_t num_variables = 0;
 };
 
+// The host-side half of a key: the eight fixed points the glue of prover.rs:76-131 reads and the multiples of delta_g1 / delta_g2
+// built for it (fixed_base.hpp).  Held by shared_ptr: the (r, s)-only half of the glue runs on a host thread of whichever context
+// prepared it (g16_prove_finalize_prepare) and keeps this alive on its own, so g16_pk_free never pulls it from under a thread of
+// ANOTHER context that shares the key (throughput mode) -- the device arrays go at once, this goes with its last reader.
 template <class C>
-struct DevicePk {
+struct KeyGlue {
     typedef typename C::G1A G1A;
     typedef typename C::G2A G2A;
     G1A alpha_g1, beta_g1, delta_g1, a_query0, b_g1_query0;
     G2A beta_g2, delta_g2, b_g2_query0;
+    // Built by the SECOND finalize over the key (~35 ms of host work once, ~0.5 ms saved per later proof): a key that proves once never pays.
+    FixedBaseTable<typename C::G1X> delta1_tab;
+    FixedBaseTable<typename C::G2X> delta2_tab;
+    std::mutex tab_mu;
+    int finalize_calls = 0;
+    // set (release) only AFTER both tables are complete; readers that are not inside tab_mu look at this flag (acquire), never at the
+    // tables' own emptiness: a key may serve two contexts at once, and a reader must not walk a table another thread is still filling
+    std::atomic<bool> tabs_ready{false};
+};
+
+template <class C>
+struct DevicePk {
+    typedef typename C::G1A G1A;
+    typedef typename C::G2A G2A;
+    std::shared_ptr<KeyGlue<C>> glue = std::make_shared<KeyGlue<C>>();
     G1A *a = nullptr, *b_g1 = nullptr, *h = nullptr, *l = nullptr;
     G2A* b_g2 = nullptr;
     uint64_t a_start = 0, a_count = 0, b_g1_start = 0, b_g1_count = 0, b_g2_start = 0, b_g2_count = 0;
@@ -193,16 +212,11 @@ struct DevicePk {
     // `count` points, row j = 2^(cj) * query.  0 = no tables (plain bases, per-window buckets).  a, b_g1, b_g2 and l share
     // the witness sort and therefore one window size; h has its own.
     int c_z = 0, c_h = 0;
-    // host: multiples of delta_g1 / delta_g2 for the glue of every proof over this key (fixed_base.hpp).  Built by the SECOND
-    // finalize over the key (~35 ms of host work once, ~0.5 ms saved per later proof): a key that proves once never pays.
-    mutable FixedBaseTable<typename C::G1X> delta1_tab;
-    mutable FixedBaseTable<typename C::G2X> delta2_tab;
-    mutable std::mutex tab_mu;
-    mutable int finalize_calls = 0;
-    // set (release) only AFTER both tables are complete; readers that are not inside tab_mu look at this flag (acquire), never at the
-    // tables' own emptiness: a key may serve two contexts at once, and a reader must not walk a table another thread is still filling
-    mutable std::atomic<bool> tabs_ready{false};
 };
+
+// every key handle gets a fresh id: a prepared finalize half is matched by id, never by the handle's address (a freed key's
+// address can be handed out again to the next g16_pk_load)
+inline uint64_t next_key_id() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1); }
 
 struct g16_pk {
     int curve;
@@ -211,6 +225,7 @@ struct g16_pk {
     std::vector<g16_pk*> subs;        // multi-device context: shard i of the key on device i (dp == nullptr)
     uint64_t dist_n = 0;              // != 0: the h shards are gathered in the block order of the distributed witness map over a
                                       // domain of dist_n points (h_query holds dist_n - 1 bases, generator.rs:168)
+    uint64_t id = next_key_id();
 };
 
 struct g16_dwm {

@@ -77,6 +77,7 @@ struct Fp30 {
     // a + K p - b    requires b < K p (roughly: b's top limb <= top(K p) - 1); bound: A + K
     template <int K>
     G16_HD Fp30 sub(const Fp30& b) const {
+        static_assert(K == 2 || K == 4 || K == 6 || K == 8 || K == 16, "redundant K p tables exist for K = 2, 4, 6, 8, 16 only");
         Fp30 r;
         G16_UNROLL for (int i = 0; i < NL; ++i) {
             const uint32_t kp = K == 2 ? P::kp2(i) : K == 4 ? P::kp4(i) : K == 6 ? P::kp6(i) : K == 8 ? P::kp8(i) : P::kp16(i);
@@ -288,6 +289,7 @@ struct Fp30 {
     // v >= c ? v - c : v   for normalised v and a normalised constant c (limbs30 of k*p)
     template <int K>
     G16_HD Fp30 cond_sub() const {
+        static_assert(K == 2 || K == 4 || K == 8 || K == 16, "k p constants exist for k = 2, 4, 8, 16 only");
         Fp30 d;
         int32_t br = 0;
         G16_UNROLL for (int i = 0; i < NL; ++i) {

@@ -123,14 +123,14 @@ struct KeyLoader {
             return G16_ERR_BAD_ARG;
         DevicePk<C>* p = new (std::nothrow) DevicePk<C>();
         if (!p) return G16_ERR_OOM;
-        p->alpha_g1 = load_pod<G1A>(v->alpha_g1);
-        p->beta_g1 = load_pod<G1A>(v->beta_g1);
-        p->delta_g1 = load_pod<G1A>(v->delta_g1);
-        p->beta_g2 = load_pod<G2A>(v->beta_g2);
-        p->delta_g2 = load_pod<G2A>(v->delta_g2);
-        p->a_query0 = load_pod<G1A>(v->a_query0);
-        p->b_g1_query0 = load_pod<G1A>(v->b_g1_query0);
-        p->b_g2_query0 = load_pod<G2A>(v->b_g2_query0);
+        p->glue->alpha_g1 = load_pod<G1A>(v->alpha_g1);
+        p->glue->beta_g1 = load_pod<G1A>(v->beta_g1);
+        p->glue->delta_g1 = load_pod<G1A>(v->delta_g1);
+        p->glue->beta_g2 = load_pod<G2A>(v->beta_g2);
+        p->glue->delta_g2 = load_pod<G2A>(v->delta_g2);
+        p->glue->a_query0 = load_pod<G1A>(v->a_query0);
+        p->glue->b_g1_query0 = load_pod<G1A>(v->b_g1_query0);
+        p->glue->b_g2_query0 = load_pod<G2A>(v->b_g2_query0);
         const bool dev = (v->flags & G16_PK_DEVICE_PTRS) != 0;
         int rc = G16_OK;
         // window tables (merged windows, msm.hip): a, b_g1, b_g2 and l share the witness sort, hence one window size

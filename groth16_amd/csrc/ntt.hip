@@ -552,26 +552,32 @@ int domain_create(int log_n, hipStream_t st, Domain<C>** out) {
     const Fr g = C::fr_generator(), g_inv = C::fr_generator_inv();
     d->zinv = (g.pow_u64((uint64_t)n) - Fr::one()).inverse();  // 1 / Z(g), r1cs_to_qap.rs:223-226 (standard form)
     int rc = G16_OK;
-    auto fail = [&](int code) { domain_destroy<C>(d); return code; };
     const size_t ntw = n > 1 ? n - 1 : 1;   // layered: 2^s entries for every stage s < log_n
     typedef Tw<typename Fr::Params> TwE;
     Fr* tw_tmp = nullptr;   // the generator writes packed words; the tables hold the butterflies' own form (Tw)
+    // every error exit gives back the staging buffer too (the OOM exits are exactly where its 32 n bytes matter); launches already
+    // queued may still be reading it, so the stream is drained first
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tw_tmp);
+        domain_destroy<C>(d);
+        return code;
+    };
     if (hipMalloc((void**)&d->tw_fwd, ntw * sizeof(TwE)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->tw_inv, ntw * sizeof(TwE)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&tw_tmp, ntw * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->s1_br, n * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     if (hipMalloc((void**)&d->s2, n * sizeof(Fr)) != hipSuccess) return fail(G16_ERR_OOM);
     for (int dir = 0; dir < 2; ++dir) {
-        if ((rc = gen_powers30<Fr>(tw_tmp, ntw, dir ? omega_inv : omega, Fr::one(), 0, st, log_n)) != G16_OK) { (void)hipFree(tw_tmp); return fail(rc); }
+        if ((rc = gen_powers30<Fr>(tw_tmp, ntw, dir ? omega_inv : omega, Fr::one(), 0, st, log_n)) != G16_OK) return fail(rc);
         hipLaunchKernelGGL((tw_convert_kernel<typename Fr::Params>), dim3((unsigned)((ntw + 255) / 256)), dim3(256), 0, st, tw_tmp,
                            reinterpret_cast<TwE*>(dir ? d->tw_inv : d->tw_fwd), ntw);
-        if (hipGetLastError() != hipSuccess) { (void)hipFree(tw_tmp); return fail(G16_ERR_HIP); }
+        if (hipGetLastError() != hipSuccess) return fail(G16_ERR_HIP);
     }
     if ((rc = gen_powers30<Fr>(d->s1_br, n, g, n_inv, log_n, st)) != G16_OK) return fail(rc);
     if ((rc = gen_powers30<Fr>(d->s2, n, g_inv, n_inv, 0, st)) != G16_OK) return fail(rc);
-    const bool sync_ok = hipStreamSynchronize(st) == hipSuccess;
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(G16_ERR_HIP);
     (void)hipFree(tw_tmp);
-    if (!sync_ok) return fail(G16_ERR_HIP);
     *out = d;
     return G16_OK;
 }

@@ -111,10 +111,10 @@ struct ProofGlue {
         if (n_parts < 1) return G16_ERR_BAD_ARG;
         return finalize_finish(finalize_prepare_core(pk, r_, s_, d1, d2), parts, n_parts, out);
     }
-    static FixedPoints fixed_points(const DevicePk<C>* pk) {
+    static FixedPoints fixed_points(const KeyGlue<C>* pk) {
         return {pk->alpha_g1, pk->beta_g1, pk->delta_g1, pk->a_query0, pk->b_g1_query0, pk->beta_g2, pk->delta_g2, pk->b_g2_query0};
     }
-    static void ensure_delta_tables(const DevicePk<C>* pk) {   // built on the second proof over a key (32 * 256 additions each)
+    static void ensure_delta_tables(KeyGlue<C>* pk) {   // built on the second proof over a key (32 * 256 additions each)
         std::lock_guard<std::mutex> lk(pk->tab_mu);
         if (!pk->tabs_ready.load(std::memory_order_relaxed) && ++pk->finalize_calls >= 2) {
             auto f1 = std::async(std::launch::async, [&]() { pk->delta1_tab.build(G1X::from_affine(pk->delta_g1)); });
@@ -125,32 +125,34 @@ struct ProofGlue {
     }
     // the tables, or nullptr while they do not exist / are being built by another context's thread (the glue then multiplies delta
     // bit by bit: correct, 0.5 ms slower, first proofs over a key only)
-    static const FixedBaseTable<G1X>* table1(const DevicePk<C>* pk) { return pk->tabs_ready.load(std::memory_order_acquire) ? &pk->delta1_tab : nullptr; }
-    static const FixedBaseTable<G2X>* table2(const DevicePk<C>* pk) { return pk->tabs_ready.load(std::memory_order_acquire) ? &pk->delta2_tab : nullptr; }
-    // start the prepared half on a host thread; g16_prove_finalize over the same (key, r, s) picks it up
+    static const FixedBaseTable<G1X>* table1(const KeyGlue<C>* pk) { return pk->tabs_ready.load(std::memory_order_acquire) ? &pk->delta1_tab : nullptr; }
+    static const FixedBaseTable<G2X>* table2(const KeyGlue<C>* pk) { return pk->tabs_ready.load(std::memory_order_acquire) ? &pk->delta2_tab : nullptr; }
+    // start the prepared half on a host thread; g16_prove_finalize over the same (key, r, s) picks it up.  The thread owns a
+    // reference to the key's host half and copies of r and s: nothing it touches can be freed or rewritten under it.
     static int prove_finalize_prepare(g16_ctx* ctx, const g16_pk* pkh, const uint64_t* r_, const uint64_t* s_) {
-        const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
+        const std::shared_ptr<KeyGlue<C>> glue = static_cast<const DevicePk<C>*>(pkh->dp)->glue;
         ctx->finprep.drop();
         auto data = std::make_shared<FinalizePrep>();
         ctx->finprep.data = data;
-        ctx->finprep.pk = pkh;
+        ctx->finprep.key_id = pkh->id;
         memcpy(ctx->finprep.r, r_, 32);
         memcpy(ctx->finprep.s, s_, 32);
-        const uint64_t* rr = ctx->finprep.r;
-        const uint64_t* ss = ctx->finprep.s;
-        ctx->finprep.fut = std::async(std::launch::async, [pk, data, rr, ss]() {
-            ensure_delta_tables(pk);
-            *data = finalize_prepare_core(fixed_points(pk), rr, ss, table1(pk), table2(pk));
+        struct RS { uint64_t r[4], s[4]; } rs;
+        memcpy(rs.r, r_, 32);
+        memcpy(rs.s, s_, 32);
+        ctx->finprep.fut = std::async(std::launch::async, [glue, data, rs]() {
+            ensure_delta_tables(glue.get());
+            *data = finalize_prepare_core(fixed_points(glue.get()), rs.r, rs.s, table1(glue.get()), table2(glue.get()));
         });
         ctx->finprep.valid = true;
         return G16_OK;
     }
     static int prove_finalize(g16_ctx* ctx, const g16_pk* pkh, const g16_partial* parts, int n_parts, const uint64_t* r_, const uint64_t* s_,
                               g16_proof* out) {
-        const DevicePk<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp);
+        KeyGlue<C>* pk = static_cast<const DevicePk<C>*>(pkh->dp)->glue.get();
         const double t0 = now_ms();
         if (n_parts < 1) return G16_ERR_BAD_ARG;
-        if (ctx->finprep.matches(pkh, r_, s_)) {   // prepared while the GPU was busy
+        if (ctx->finprep.matches(pkh->id, r_, s_)) {   // prepared while the GPU was busy
             ctx->finprep.fut.get();
             const std::shared_ptr<void> keep = ctx->finprep.data;
             ctx->finprep.valid = false;
