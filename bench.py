@@ -35,9 +35,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import groth16_amd as g  # noqa: E402
-from groth16_amd.binding import (CURVE_ID, FQ_LIMBS, CsrViewC, DiagC, ParamsViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC,  # noqa: E402
+from groth16_amd.binding import (CURVE_ID, FQ_LIMBS, CsrViewC, DiagC, ParamsViewC, PartialC, PkInfoC, PkViewC, ProofC, QueryC, TimingsC,  # noqa: E402
                                  ToxicWasteC, ptr32, ptr64)
-from groth16_amd.groth16 import _MODULUS_R, DistributedWitnessMap, dist_h_indices  # noqa: E402
+from groth16_amd.groth16 import _MODULUS_R, DistributedWitnessMap, bucket_h_indices, dist_h_indices  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -47,17 +47,22 @@ def shard_range(n, idx, cnt):
 
 
 class DeviceProver:
-    """SYN(k) circuit + proving-key shard, everything resident on one GPU.  key = "valid": the CRS of the circuit, generated
-    on the GPU from seeded toxic waste; "synthetic": distinct non-identity points (any points give the same prover work)."""
+    """SYN(k) circuit + this rank's part of the proving key, everything resident on one GPU.  key = "valid": the CRS of the circuit,
+    generated on the GPU from seeded toxic waste; "synthetic": distinct non-identity points (any points give the same prover work).
+    mode = "base": the rank holds a contiguous range of every MSM base array; "bucket": the WHOLE key as window tables and the
+    buckets b mod world == rank of every MSM (g16_pk_load_bucket_shard)."""
 
-    def __init__(self, curve, k, seed, rank, world, device, key="valid", dist_wm=False):
-        """dist_wm: this rank runs its part of the distributed witness map and holds the h_query shard in block order"""
+    def __init__(self, curve, k, seed, rank, world, device, key="valid", dist_wm=False, mode="base"):
+        """dist_wm: this rank runs its part of the distributed witness map and holds h_query in the order its h arrives in"""
         self.curve, self.k, self.rank, self.world, self.key = curve, k, rank, world, key
+        self.mode = mode if world > 1 else "base"
+        self.sim = False   # --sim-shards: the h all-gather of a bucket-space shard is simulated by local copies
         self.dwm, self.dwm_ms = None, 0.0
         self.lib = g.lib()
         c = self.lib.c
         L = FQ_LIMBS[curve]
         self.L = L
+        self.device = device
         self.ctx = C.c_void_p()
         self.lib.check(c.g16_ctx_create(CURVE_ID[curve], device, C.byref(self.ctx)))
         nc = (1 << k) - 2
@@ -71,80 +76,105 @@ class DeviceProver:
         self.lib.check(c.g16_synth_circuit(CURVE_ID[curve], k, seed, ptr64(z), ptr64(rp), ptr32(cols[0]), ptr32(cols[1]),
                                            ptr32(cols[2]), ptr64(val)))
         self.z_host, self.csr_host = z, (rp, cols, val)
-        views = (CsrViewC * 3)(*[CsrViewC(ptr64(rp), ptr32(cols[i]), ptr64(val)) for i in range(3)])
+        self._views = (CsrViewC * 3)(*[CsrViewC(ptr64(rp), ptr32(cols[i]), ptr64(val)) for i in range(3)])
         self.ck = C.c_void_p()
-        self.lib.check(c.g16_circuit_load(self.ctx, views, self.nin, nc, self.nvars, C.byref(self.ck)))
+        self.lib.check(c.g16_circuit_load(self.ctx, self._views, self.nin, nc, self.nvars, C.byref(self.ck)))
         self.z_dev = torch.from_numpy(z.view(np.int64)).to(f"cuda:{device}")
-        # ---- proving key shard: bases generated straight into HBM
+        self.seed = seed
+        self.seeds = dict(a=101, b1=102, b2=103, h=104, l=105, fixed1=106, fixed2=107)
+        self._full = None
+        self.fixed = None
+        # ---- this rank's part of the proving key: bases generated straight into HBM
+        self.pk, self.bufs, self.ranges, self.pk_load_s = self.load_key(rank, world, self.mode, dist_wm)
+        if dist_wm:
+            self.dwm = DistributedWitnessMap(self.lib, self.ctx, self.ck, rank, world, f"cuda:{device}")
+        # fixed non-zero r, s (zero-knowledge randomness is an input: prover.rs:173-178)
+        self.r = z[2].copy()
+        self.s = z[3].copy()
+
+    def _synth(self, g2, sd, first, cnt):
+        words = (4 if g2 else 2) * self.L
+        t = torch.empty((max(cnt, 1), words), dtype=torch.int64, device=f"cuda:{self.device}")
+        self.lib.check(self.lib.c.g16_synth_bases(self.ctx, int(g2), sd, first, cnt, C.c_void_p(t.data_ptr())))
+        return t
+
+    def _generate_valid_key(self):
+        """Groth16::generate_parameters_with_qap (generator.rs:47-208) straight into HBM; every rank derives the same key from the
+        same seed and keeps its part"""
+        c, L, dev = self.lib.c, self.L, f"cuda:{self.device}"
+        hlen, w = self.n - 1, self.nvars - self.nin
+        rs = np.random.RandomState(20240 + self.seed)
+        mod = _MODULUS_R[self.curve]
+
+        def rand_fr():
+            v = int.from_bytes(rs.bytes(64), "little") % mod or 1
+            v = (v << 256) % mod   # Montgomery form
+            return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+        tw = ToxicWasteC()
+        for name in ("alpha", "beta", "gamma", "delta", "t"):
+            getattr(tw, name)[:] = rand_fr()
+        gen1 = self._synth(False, self.seeds["fixed1"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1).copy()
+        gen2 = self._synth(True, self.seeds["fixed2"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1).copy()
+        full = dict(a=torch.empty((self.nvars, 2 * L), dtype=torch.int64, device=dev),
+                    b1=torch.empty((self.nvars, 2 * L), dtype=torch.int64, device=dev),
+                    b2=torch.empty((self.nvars, 4 * L), dtype=torch.int64, device=dev),
+                    h=torch.empty((hlen, 2 * L), dtype=torch.int64, device=dev), l=torch.empty((w, 2 * L), dtype=torch.int64, device=dev))
+        fx = dict(alpha_g1=np.zeros(2 * L, dtype=np.uint64), beta_g1=np.zeros(2 * L, dtype=np.uint64), delta_g1=np.zeros(2 * L, dtype=np.uint64),
+                  beta_g2=np.zeros(4 * L, dtype=np.uint64), delta_g2=np.zeros(4 * L, dtype=np.uint64))
+        self.vk_rest = dict(gamma_g2=np.zeros(4 * L, dtype=np.uint64), gamma_abc_g1=np.zeros((self.nin, 2 * L), dtype=np.uint64))
+        out = ParamsViewC(ptr64(fx["alpha_g1"]), ptr64(fx["beta_g1"]), ptr64(fx["delta_g1"]), ptr64(fx["beta_g2"]), ptr64(fx["delta_g2"]),
+                          ptr64(self.vk_rest["gamma_g2"]), ptr64(self.vk_rest["gamma_abc_g1"]), C.c_void_p(full["a"].data_ptr()),
+                          C.c_void_p(full["b1"].data_ptr()), C.c_void_p(full["b2"].data_ptr()), C.c_void_p(full["h"].data_ptr()),
+                          C.c_void_p(full["l"].data_ptr()), 1)
+        self.lib.check(c.g16_generate_parameters(self.ctx, self._views, self.nin, self.nc, self.nvars, C.byref(tw), ptr64(gen1), ptr64(gen2),
+                                                 C.byref(out)))
+        u64 = lambda t: t.cpu().numpy().view(np.uint64).reshape(-1).copy()  # noqa: E731
+        fx.update(a0=u64(full["a"][0]), b10=u64(full["b1"][0]), b20=u64(full["b2"][0]))
+        self.fixed = fx
+        self._full = full
+
+    def load_key(self, rank, world, mode, dist_wm):
+        """rank's part of the key under `mode` onto the GPU: (g16_pk handle, the standard-form bases it was built from, the index
+        ranges, seconds of g16_pk_load).  The headline prover calls it once; the projected-scaling leg again per simulated cut."""
+        c, L, dev = self.lib.c, self.L, f"cuda:{self.device}"
+        bucket = mode == "bucket" and world > 1
         m, w, hlen = self.nvars - 1, self.nvars - self.nin, self.n - 1
-        a_lo, a_hi = shard_range(m, rank, world)
+        a_lo, a_hi = (0, m) if bucket else shard_range(m, rank, world)
         l_lo = min(w, max(0, a_lo - (self.nin - 1)))
         l_hi = min(w, max(0, a_hi - (self.nin - 1)))
-        h_lo, h_hi = shard_range(hlen, rank, world)
-        dev = f"cuda:{device}"
+        h_lo, h_hi = (0, hlen) if bucket else shard_range(hlen, rank, world)
         h_sel = None
-        if dist_wm:   # h_query gathered in the block order the distributed map leaves h in (the last index, n - 1, has no base)
-            idx = dist_h_indices(self.n, rank, world)
+        if dist_wm:
+            # h_query in the order the distributed map leaves h in: this rank's block (base-range shard), or -- bucket-space shard:
+            # every rank folds ALL of h -- the ranks' blocks back to back, as the all-gather delivers them (the last index, n - 1,
+            # has no base)
+            idx = bucket_h_indices(self.n, world) if bucket else dist_h_indices(self.n, rank, world)
             h_sel = torch.from_numpy(idx[idx < hlen]).to(dev)
             h_lo, h_hi = 0, int(h_sel.numel())
-        self.ranges = dict(a=(a_lo, a_hi), l=(l_lo, l_hi), h=(h_lo, h_hi))
-
-        def synth(g2, sd, first, cnt):
-            words = (4 if g2 else 2) * L
-            t = torch.empty((max(cnt, 1), words), dtype=torch.int64, device=dev)
-            self.lib.check(c.g16_synth_bases(self.ctx, int(g2), sd, first, cnt, C.c_void_p(t.data_ptr())))
-            return t
-
-        self.seeds = dict(a=101, b1=102, b2=103, h=104, l=105, fixed1=106, fixed2=107)
-        if key == "valid":
-            # Groth16::generate_parameters_with_qap (generator.rs:47-208) straight into HBM; every rank derives the same key
-            # from the same seed and keeps its shard
-            rs = np.random.RandomState(20240 + seed)
-            mod = _MODULUS_R[curve]
-
-            def rand_fr():
-                v = int.from_bytes(rs.bytes(64), "little") % mod or 1
-                v = (v << 256) % mod   # Montgomery form
-                return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
-
-            tw = ToxicWasteC()
-            for name in ("alpha", "beta", "gamma", "delta", "t"):
-                getattr(tw, name)[:] = rand_fr()
-            gen1 = synth(False, self.seeds["fixed1"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1).copy()
-            gen2 = synth(True, self.seeds["fixed2"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1).copy()
-            full = dict(a=torch.empty((self.nvars, 2 * L), dtype=torch.int64, device=dev),
-                        b1=torch.empty((self.nvars, 2 * L), dtype=torch.int64, device=dev),
-                        b2=torch.empty((self.nvars, 4 * L), dtype=torch.int64, device=dev),
-                        h=torch.empty((hlen, 2 * L), dtype=torch.int64, device=dev), l=torch.empty((w, 2 * L), dtype=torch.int64, device=dev))
-            fx = dict(alpha_g1=np.zeros(2 * L, dtype=np.uint64), beta_g1=np.zeros(2 * L, dtype=np.uint64), delta_g1=np.zeros(2 * L, dtype=np.uint64),
-                      beta_g2=np.zeros(4 * L, dtype=np.uint64), delta_g2=np.zeros(4 * L, dtype=np.uint64))
-            self.vk_rest = dict(gamma_g2=np.zeros(4 * L, dtype=np.uint64), gamma_abc_g1=np.zeros((self.nin, 2 * L), dtype=np.uint64))
-            out = ParamsViewC(ptr64(fx["alpha_g1"]), ptr64(fx["beta_g1"]), ptr64(fx["delta_g1"]), ptr64(fx["beta_g2"]), ptr64(fx["delta_g2"]),
-                              ptr64(self.vk_rest["gamma_g2"]), ptr64(self.vk_rest["gamma_abc_g1"]), C.c_void_p(full["a"].data_ptr()),
-                              C.c_void_p(full["b1"].data_ptr()), C.c_void_p(full["b2"].data_ptr()), C.c_void_p(full["h"].data_ptr()),
-                              C.c_void_p(full["l"].data_ptr()), 1)
-            self.lib.check(c.g16_generate_parameters(self.ctx, views, self.nin, nc, self.nvars, C.byref(tw), ptr64(gen1), ptr64(gen2),
-                                                     C.byref(out)))
+        ranges = dict(a=(a_lo, a_hi), l=(l_lo, l_hi), h=(h_lo, h_hi))
+        if self.key == "valid":
+            if self._full is None:
+                self._generate_valid_key()
+            full = self._full
             bufs = dict(a=full["a"][1 + a_lo: 1 + a_hi], b1=full["b1"][1 + a_lo: 1 + a_hi], b2=full["b2"][1 + a_lo: 1 + a_hi],
                         h=full["h"][h_lo: h_hi] if h_sel is None else full["h"].index_select(0, h_sel), l=full["l"][l_lo: l_hi])
-            u64 = lambda t: t.cpu().numpy().view(np.uint64).reshape(-1).copy()  # noqa: E731
-            fx.update(a0=u64(full["a"][0]), b10=u64(full["b1"][0]), b20=u64(full["b2"][0]))
-            self.fixed = fx
-            self._full = full   # the slices above are views of these
         else:
             # index 0 of the a/b generators is query[0]; MSM index i is generator index 1 + i
+            sy, sd = self._synth, self.seeds
             bufs = dict(
-                a=synth(False, self.seeds["a"], 1 + a_lo, a_hi - a_lo), b1=synth(False, self.seeds["b1"], 1 + a_lo, a_hi - a_lo),
-                b2=synth(True, self.seeds["b2"], 1 + a_lo, a_hi - a_lo),
-                h=synth(False, self.seeds["h"], h_lo, h_hi - h_lo) if h_sel is None else synth(False, self.seeds["h"], 0, hlen).index_select(0, h_sel),
-                l=synth(False, self.seeds["l"], l_lo, l_hi - l_lo))
-            q0a = synth(False, self.seeds["a"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
-            q0b1 = synth(False, self.seeds["b1"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
-            q0b2 = synth(True, self.seeds["b2"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
-            f1 = synth(False, self.seeds["fixed1"], 0, 3).cpu().numpy().view(np.uint64)  # alpha_g1, beta_g1, delta_g1
-            f2 = synth(True, self.seeds["fixed2"], 0, 2).cpu().numpy().view(np.uint64)   # beta_g2, delta_g2
-            self.fixed = dict(alpha_g1=f1[0].copy(), beta_g1=f1[1].copy(), delta_g1=f1[2].copy(), beta_g2=f2[0].copy(),
-                              delta_g2=f2[1].copy(), a0=q0a.copy(), b10=q0b1.copy(), b20=q0b2.copy())
+                a=sy(False, sd["a"], 1 + a_lo, a_hi - a_lo), b1=sy(False, sd["b1"], 1 + a_lo, a_hi - a_lo),
+                b2=sy(True, sd["b2"], 1 + a_lo, a_hi - a_lo),
+                h=sy(False, sd["h"], h_lo, h_hi - h_lo) if h_sel is None else sy(False, sd["h"], 0, hlen).index_select(0, h_sel),
+                l=sy(False, sd["l"], l_lo, l_hi - l_lo))
+            if self.fixed is None:
+                q0a = sy(False, sd["a"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
+                q0b1 = sy(False, sd["b1"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
+                q0b2 = sy(True, sd["b2"], 0, 1).cpu().numpy().view(np.uint64).reshape(-1)
+                f1 = sy(False, sd["fixed1"], 0, 3).cpu().numpy().view(np.uint64)  # alpha_g1, beta_g1, delta_g1
+                f2 = sy(True, sd["fixed2"], 0, 2).cpu().numpy().view(np.uint64)   # beta_g2, delta_g2
+                self.fixed = dict(alpha_g1=f1[0].copy(), beta_g1=f1[1].copy(), delta_g1=f1[2].copy(), beta_g2=f2[0].copy(),
+                                  delta_g2=f2[1].copy(), a0=q0a.copy(), b10=q0b1.copy(), b20=q0b2.copy())
 
         def q(t, lo, hi):
             return QueryC(t.data_ptr() if hi > lo else None, hi - lo, lo)
@@ -153,17 +183,21 @@ class DeviceProver:
         view = PkViewC(ptr64(fx["alpha_g1"]), ptr64(fx["beta_g1"]), ptr64(fx["delta_g1"]), ptr64(fx["beta_g2"]), ptr64(fx["delta_g2"]),
                        ptr64(fx["a0"]), ptr64(fx["b10"]), ptr64(fx["b20"]), q(bufs["a"], a_lo, a_hi), q(bufs["b1"], a_lo, a_hi),
                        q(bufs["b2"], a_lo, a_hi), q(bufs["h"], h_lo, h_hi), q(bufs["l"], l_lo, l_hi), 1)
-        self.pk = C.c_void_p()
+        pk = C.c_void_p()
         torch.cuda.synchronize()
         t_load = time.perf_counter()
-        self.lib.check(c.g16_pk_load(self.ctx, C.byref(view), C.byref(self.pk)))
-        self.pk_load_s = time.perf_counter() - t_load   # the "cold" cost: window tables built from device-resident bases, once per key
-        self.bufs = bufs  # standard-form copies kept for the CPU-baseline download (the library holds its own)
-        if dist_wm:
-            self.dwm = DistributedWitnessMap(self.lib, self.ctx, self.ck, rank, world, dev)
-        # fixed non-zero r, s (zero-knowledge randomness is an input: prover.rs:173-178)
-        self.r = z[2].copy()
-        self.s = z[3].copy()
+        if bucket:
+            self.lib.check(c.g16_pk_load_bucket_shard(self.ctx, C.byref(view), rank, world, C.byref(pk)))
+        else:
+            self.lib.check(c.g16_pk_load(self.ctx, C.byref(view), C.byref(pk)))
+        # the "cold" cost: window tables built from device-resident bases, once per key.  `bufs`: standard-form copies kept for the
+        # CPU-baseline download (the library holds its own)
+        return pk, bufs, ranges, time.perf_counter() - t_load
+
+    def pk_info(self):
+        out = PkInfoC()
+        self.lib.check(self.lib.c.g16_pk_get_info(self.pk, C.byref(out)))
+        return out.as_dict()
 
     def partial(self, host_z=None, dist=None):
         """host_z = None: the witness is already in HBM (the timed configuration); else a host pointer (int) to upload from.
@@ -177,9 +211,14 @@ class DeviceProver:
             if host_z is None and not os.environ.get("G16_BENCH_NO_PREPARE"):   # the witness sort goes into the queues ahead of the map's stages
                 self.lib.check(self.lib.c.g16_prove_partial_prepare(self.ctx, self.pk, self.ck, zp, self.nvars))
             h = self.dwm.run(self.z_dev.data_ptr() if host_z is None else host_z, self.nvars, host_z is None, dist)
+            h_len = self.dwm.M
+            if self.mode == "bucket" and self.world > 1:
+                # a bucket-space shard folds ALL of h: one all-gather of the ranks' blocks (RCCL over xGMI; n / world Fr per rank)
+                h = self.dwm.all_gather_h(dist, simulate=self.sim)
+                h_len = self.dwm.M * self.world
             self.dwm_ms = 1e3 * (time.perf_counter() - t0)
             self.lib.check(self.lib.c.g16_prove_partial_h(self.ctx, self.pk, self.ck, zp, self.nvars, 1 if host_z is None else 0,
-                                                          C.c_void_p(h.data_ptr()), self.dwm.M, 0, C.byref(part)))
+                                                          C.c_void_p(h.data_ptr()), h_len, 0, C.byref(part)))
             return part
         self.lib.check(self.lib.c.g16_prove_partial(self.ctx, self.pk, self.ck, zp, self.nvars, 1 if host_z is None else 0, 0, C.byref(part)))
         return part
@@ -339,6 +378,104 @@ def cpu_baseline(curve, k_cpu, seed, threads, key="valid", reuse=None):
                 seconds=dt, phases={k_: round(v, 3) for k_, v in phases.items()}, gpu_proof_matches_cpu=match)
 
 
+def sim_share(p, n_ranks, mode, steps, warmup, use_dwm, ranks=(0,)):
+    """DIAGNOSTIC: one rank's share of an n_ranks-way sharded proof, measured on THIS GPU -- the rank's stages of the distributed witness
+    map with the exchanges (and a bucket-space shard's h all-gather) replaced by device copies of the same size, its five partial sums,
+    then the finalize over n_ranks records.  RCCL / xGMI latencies are NOT in it.  mode "bucket" re-labels the resident whole-key tables
+    (g16_pk_rebind_bucket_shard: they do not depend on the rank) when p holds them; otherwise the shard is loaded from the key
+    material in HBM and freed again.  Returns the slowest of `ranks`."""
+    lib, c = p.lib, p.lib.c
+    saved = (p.pk, p.dwm, p.rank, p.world, p.mode, p.sim, p.bufs, p.ranges)
+    whole = p.world == 1 or p.mode == "bucket"
+    rebind = mode == "bucket" and whole and p.pk_info()["window_bits_z"] > 0
+    worst = None
+    try:
+        for r in ranks:
+            dwm = pk = None
+            try:
+                if rebind:
+                    lib.check(c.g16_pk_rebind_bucket_shard(saved[0], r, n_ranks))
+                    pk, load_s = saved[0], 0.0
+                else:
+                    pk, p.bufs, p.ranges, load_s = p.load_key(r, n_ranks, mode, use_dwm)
+                if use_dwm:
+                    dwm = DistributedWitnessMap(lib, p.ctx, p.ck, r, n_ranks, f"cuda:{p.device}")
+                p.pk, p.dwm, p.rank, p.world, p.mode, p.sim = pk, dwm, r, n_ranks, mode, True
+                for _ in range(warmup):
+                    p.partial()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    part = p.partial()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                p.finalize([part] * n_ranks)
+                t1 = time.perf_counter()
+                p.finalize([part] * n_ranks)
+                fin = time.perf_counter() - t1
+                got = dict(rank=r, partial_ms=1e3 * dt, finalize_ms=1e3 * fin, phases=p.timings(), pk_load_s=round(load_s, 3),
+                           enqueue_ms=p.dwm_ms if dwm is not None else None)
+                if worst is None or got["partial_ms"] > worst["partial_ms"]:
+                    worst = got
+            finally:
+                if dwm is not None:
+                    dwm.close()
+                if pk is not None and not rebind:
+                    c.g16_pk_free(pk)
+    finally:
+        p.pk, p.dwm, p.rank, p.world, p.mode, p.sim, p.bufs, p.ranges = saved
+        if rebind:
+            lib.check(c.g16_pk_rebind_bucket_shard(p.pk, p.rank if p.mode == "bucket" else 0, p.world if p.mode == "bucket" else 1))
+    return worst
+
+
+def projected_scaling(p, single_ms, steps, dist_wm_ok):
+    """PROJECTION, not a measurement of N GPUs (none has been available to this repository): per-rank share of the SAME proof at 2, 4, 8
+    ranks under both ways of cutting the MSMs, each measured on this one GPU (sim_share), and single_ms / share.  What it leaves out:
+    RCCL latency of the map's 7 all-to-all calls, of the h all-gather (bucket mode) and of the record all-gather."""
+    out = dict(note="projection from ONE GPU: rank share = the rank's own stages with every exchange replaced by a device copy of the same "
+                    "bytes; no RCCL / xGMI latency; projected_speedup = single-GPU ms_per_step / (partial_ms + finalize_ms)",
+               single_gpu_ms=single_ms, points=[])
+    for mode in ("bucket", "base"):
+        for n_ranks in (2, 4, 8):
+            try:
+                ranks = tuple(range(n_ranks)) if mode == "bucket" else (0,)
+                sh = sim_share(p, n_ranks, mode, max(2, min(steps, 4)), 1, dist_wm_ok(n_ranks, p.k), ranks)
+                share = sh["partial_ms"] + sh["finalize_ms"]
+                out["points"].append(dict(n_gpus=n_ranks, shard_mode=mode, rank_share_ms=round(share, 3), partial_ms=round(sh["partial_ms"], 3),
+                                          finalize_ms=round(sh["finalize_ms"], 3), projected_speedup=round(single_ms / share, 3),
+                                          projected_value=p.nc / (share * 1e-3), ranks_measured=len(ranks),
+                                          bucket_pass_ms=round(sh["phases"]["bucket_pass_ms"], 3),
+                                          window_bits=int(sh["phases"]["window_bits"]), windows=int(sh["phases"]["windows"])))
+            except Exception as e:  # noqa: BLE001 -- a projection must never take the headline line down
+                out["points"].append(dict(n_gpus=n_ranks, shard_mode=mode, error=repr(e)))
+    return out
+
+
+def pick_shard_mode(want, world, k, curve, device, dist):
+    """how the MSMs are cut over the ranks.  auto: bucket-space shards (whole window tables on every GPU, buckets divided: the bucket
+    reductions shrink with the rank count too) whenever the tables of the WHOLE key fit in this GPU's free HBM with room for the
+    per-proof arena, else base-range shards (1 / world of the tables per GPU).  Every rank must decide alike: MIN over the ranks."""
+    if world == 1:
+        return "base", "single GPU"
+    why = f"--shard-mode {want}"
+    mode = want
+    if want == "auto":
+        g1 = 2 * FQ_LIMBS[curve] * 8
+        key_bytes = (1 << k) * 6 * g1                     # a, b_g1, l, h (G1) + b_g2 (G2 = 2 G1)
+        rows = 13 if k >= 20 else 32                      # window tables: W rows (c = 20: 13; small keys use small windows, more rows)
+        need = int(rows * key_bytes * 1.08) + 3 * key_bytes + (8 << 30)
+        free, _total = torch.cuda.mem_get_info(device)
+        mode = "bucket" if need < free else "base"
+        why = f"auto: whole-key window tables need ~{need / 2**30:.0f} GiB, {free / 2**30:.0f} GiB free -> {mode}"
+    if dist is not None and world > 1:
+        flag = torch.tensor([1 if mode == "bucket" else 0], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if mode == "bucket" and int(flag.item()) == 0:
+            mode, why = "base", why + " (another rank cannot hold the whole key)"
+    return mode, why
+
+
 def run_configs4(args, dist, device, rank, world, local_rank, barrier, dist_wm_ok):
     """BASELINE.json configs[4]: synthetic R1CS with 2^24 constraints, BLS12-381, MSM bases sharded over the ranks (+ the
     distributed witness map), same timed bracket as the headline.  Every rank calls this; a rank whose setup fails reports it
@@ -348,16 +485,20 @@ def run_configs4(args, dist, device, rank, world, local_rank, barrier, dist_wm_o
     try:
         # synthetic bases (generated on the GPU; any distinct points give the same prover work): the valid CRS of a 2^24 circuit costs
         # every rank ~15 s of HOST scalar work, eight ranks share one CPU quota, and this leg must not endanger the headline line
-        p4 = DeviceProver(args.curve, k4, 1, rank, world, local_rank, "synthetic", dist_wm=dist_wm_ok(world, k4))
+        mode4, why4 = pick_shard_mode(args.shard_mode, world, k4, args.curve, local_rank, None)   # no collective before the error protocol
+        p4 = DeviceProver(args.curve, k4, 1, rank, world, local_rank, "synthetic", dist_wm=dist_wm_ok(world, k4), mode=mode4)
         torch.cuda.synchronize()
     except Exception as e:  # noqa: BLE001
         err = repr(e)
-    ok = torch.tensor([0 if err else 1], dtype=torch.int64, device=device)
+    # one all-reduce carries both "my setup worked" and "I hold a bucket-space shard": a rank that could not hold the whole key fails
+    # its load (no silent fall-back in that mode), and ranks that disagree on the mode must not meet in a data-path collective
+    ok = torch.tensor([0 if err else 1, 0 if err else (1 if p4.mode == "bucket" else 0), 0 if err else (0 if p4.mode == "bucket" else 1)],
+                      dtype=torch.int64, device=device)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
+    if int(ok[0].item()) == 0 or (int(ok[1].item()) == 0 and int(ok[2].item()) == 0):
         if p4 is not None:
             p4.close()
-        return {"error": err or "setup failed on another rank"}
+        return {"error": err or ("setup failed on another rank" if int(ok[0].item()) == 0 else "ranks chose different shard modes")}
     steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
     proof = None
     for _ in range(warmup):
@@ -378,7 +519,9 @@ def run_configs4(args, dist, device, rank, world, local_rank, barrier, dist_wm_o
     import hashlib
 
     res = dict(workload=f"SYN(k={k4}) synthetic R1CS, {p4.nc} constraints, FFT domain 2^{k4}, {args.curve}, full create_proof, synthetic-bases proving key, "
-                        f"MSM bases sharded over {world} ranks" + (" + distributed witness map" if p4.dwm is not None else " (witness map replicated)"),
+                        + (f"MSM buckets sharded over {world} ranks (whole window tables per GPU)" if p4.mode == "bucket" else f"MSM bases sharded over {world} ranks")
+                        + ((" + distributed witness map" + (" + h all-gather" if p4.mode == "bucket" else "")) if p4.dwm is not None else " (witness map replicated)"),
+               shard_mode=p4.mode, shard_mode_reason=why4, pk=p4.pk_info(),
                log2_domain=k4, constraints=p4.nc, n_gpus=world, steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps,
                value=p4.nc * steps / dt, unit="constraints/s", pk_load_s=round(p4.pk_load_s, 3), ranks_agree_on_proof=same,
                proof_sha256=hashlib.sha256(proof.tobytes()).hexdigest(), phases_ms_rank0=p4.timings())
@@ -423,6 +566,12 @@ def main():
                          "sharded over the ranks) and report it as the `configs4` field of the same JSON line; auto = when --gpus is 8 "
                          "and --log2 is the headline 22")
     ap.add_argument("--configs4-log2", type=int, default=24, help=argparse.SUPPRESS)   # tests shrink it
+    ap.add_argument("--shard-mode", choices=["auto", "base", "bucket"], default=os.environ.get("G16_BENCH_SHARD_MODE", "auto"),
+                    help="N > 1: how the five MSMs are cut over the ranks -- base: contiguous ranges of the bases (1/N of the window tables per GPU); "
+                         "bucket: the whole tables on every GPU, the BUCKETS divided (b mod N == rank), so the bucket reductions shrink with N "
+                         "too; auto (default): bucket when the whole key's tables fit in free HBM, else base")
+    ap.add_argument("--no-projection", action="store_true", help="N = 1: skip the projected_scaling leg (per-rank shares at 2 / 4 / 8 ranks "
+                                                                  "measured on this GPU)")
     ap.add_argument("--sim-shards", type=int, default=0,
                     help="DIAGNOSTIC, not a benchmark: time one rank's share of an N-way sharded proof on a single GPU "
                          "(shard 0 of N, no exchange); the JSON line is tagged and must not be read as throughput")
@@ -501,7 +650,10 @@ def main():
 
     if args.sim_shards:
         assert world == 1
-        p = DeviceProver(args.curve, args.log2, 1, 0, args.sim_shards, local_rank, args.key, dist_wm=dist_wm_ok(args.sim_shards))
+        mode = "base" if args.shard_mode == "auto" else args.shard_mode
+        use_dwm = dist_wm_ok(args.sim_shards)
+        p = DeviceProver(args.curve, args.log2, 1, 0, args.sim_shards, local_rank, args.key, dist_wm=use_dwm, mode=mode)
+        p.sim = True
         for _ in range(args.warmup):
             p.partial()
         torch.cuda.synchronize()
@@ -510,17 +662,21 @@ def main():
             part = p.partial()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
+        p.finalize([part] * args.sim_shards)
         t1 = time.perf_counter()
         p.finalize([part] * args.sim_shards)
         fin = time.perf_counter() - t1
         print(json.dumps({"diagnostic": "per-rank share of a sharded proof (NOT a throughput number)", "sim_shards": args.sim_shards,
-                          "log2": args.log2, "partial_ms": 1e3 * dt, "finalize_ms": 1e3 * fin, "phases": p.timings(),
-                          "witness_map": ("distributed: rank 0's four stages, the three exchanges replaced by local copies, enqueued "
+                          "shard_mode": p.mode, "log2": args.log2, "partial_ms": 1e3 * dt, "finalize_ms": 1e3 * fin, "phases": p.timings(),
+                          "pk": p.pk_info(), "pk_load_s": round(p.pk_load_s, 3),
+                          "witness_map": ("distributed: rank 0's four stages, the three exchanges" +
+                                          (" and the h all-gather" if p.mode == "bucket" else "") + " replaced by local copies, enqueued "
                                           f"without host synchronisation ({p.dwm_ms:.2f} ms of host time)") if p.dwm is not None else "replicated"}),
               flush=True)
         return
     t_setup = time.perf_counter()
-    p = DeviceProver(args.curve, args.log2, 1, rank, world, local_rank, args.key, dist_wm=dist_wm_ok(world))
+    shard_mode, shard_why = pick_shard_mode(args.shard_mode, world, args.log2, args.curve, local_rank, dist)
+    p = DeviceProver(args.curve, args.log2, 1, rank, world, local_rank, args.key, dist_wm=dist_wm_ok(world), mode=shard_mode)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     proof = None
@@ -583,7 +739,10 @@ def main():
         # N * (96 B affine base + 32 B scalar), N = points in this rank's shard.
         n_pts = p.ranges["a"][1] - p.ranges["a"][0]
         base_bytes = 2 * FQ_LIMBS[args.curve] * 8
-        alg_bytes = n_pts * (base_bytes + 32)
+        # (bucket-space shard: the rank folds 1 / world of the (point, window) entries of ALL points -- SURVEY 8(d): the sharded terms
+        # divide by the GPU count)
+        bucket_div = world if p.mode == "bucket" else 1
+        alg_bytes = n_pts * (base_bytes + 32) // bucket_div
         avg_ms = float(np.mean(bucket_g1)) if bucket_g1 else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, committed under profiles/);
@@ -610,13 +769,13 @@ def main():
         if n_windows:
             dg = DiagC()
             p.lib.check(p.lib.c.g16_diag_valu(p.ctx, C.byref(dg)))
-            mads = float(n_pts) * n_windows * dg.mads_per_add_g1
+            mads = float(n_pts) * n_windows * dg.mads_per_add_g1 / bucket_div
             valu = dict(kind="v_mad_u64_u32 issue (integer VALU)", mads_per_launch=mads, achieved_Tmad_s=mads / (avg_ms * 1e-3) / 1e12,
                         measured_peak_Tmad_s=dg.mad_per_s / 1e12, frac=mads / (avg_ms * 1e-3) / dg.mad_per_s,
                         peak_source="g16_diag_valu: mad_rate_kernel timed in this run", mads_per_mixed_add=dg.mads_per_add_g1,
                         mads_per_field_product=dg.mads_per_product, limbs30=dg.limbs, window_bits=int(last_tm.get("window_bits", 0)),
-                        windows=n_windows, points_folded_per_launch=n_pts * n_windows,
-                        g2=dict(mads_per_mixed_add=dg.mads_per_add_g2, achieved_Tmad_s=float(n_pts) * n_windows * dg.mads_per_add_g2 /
+                        windows=n_windows, points_folded_per_launch=n_pts * n_windows // bucket_div,
+                        g2=dict(mads_per_mixed_add=dg.mads_per_add_g2, achieved_Tmad_s=float(n_pts) * n_windows * dg.mads_per_add_g2 / bucket_div /
                                 (float(np.mean(bucket_g2)) * 1e-3) / 1e12 if bucket_g2 and np.mean(bucket_g2) > 0 else None))
         # second object for the transforms (2 * 32 * n algorithmic bytes per NTT, seven per proof), from the
         # HIP-event timers around them inside the witness map
@@ -650,8 +809,13 @@ def main():
                        "curve": args.curve, "log2_domain": args.log2, "constraints": p.nc, "key": args.key,
                        "untimed_setup_s": round(t_setup, 2), "pk_load_s": round(p.pk_load_s, 3),
                        "witness": "resident in HBM at entry (see value_incl_h2d for the PCIe-inclusive rates)",
-                       "parallelism": (f"msm-base-shard x{world}" + (" + distributed witness map (3 all-to-all)" if p.dwm is not None
-                                                                             else " (witness map replicated)")) if world > 1 else "single-gpu"},
+                       "parallelism": ((f"msm-bucket-shard x{world} (whole window tables per GPU, buckets b mod {world} == rank)" if p.mode == "bucket"
+                                        else f"msm-base-shard x{world}") +
+                                       ((" + distributed witness map (3 all-to-all)" + (" + h all-gather" if p.mode == "bucket" else ""))
+                                        if p.dwm is not None else " (witness map replicated)")) if world > 1 else "single-gpu",
+                       "shard_mode": p.mode if world > 1 else None, "shard_mode_reason": shard_why if world > 1 else None,
+                       # how the key is held: window tables, or plain bases and WHY (a slower prover: c <= 16, more windows)
+                       "pk": p.pk_info()},
             "roofline": roofline, "roofline_ntt": roofline_ntt, "value_incl_h2d": h2d,
             # SURVEY.md 8(d) defines the metric with the witness on the HOST at entry; the bench contract defines `value` with the
             # inputs resident in HBM.  Both are reported: `value` above (resident), this one with the 32 B x num_variables upload
@@ -664,6 +828,13 @@ def main():
             out["collective_backend"] = "rccl (torch.distributed nccl)" if backend == "nccl" else backend
             out["ranks"] = ranks_seen
             out["distinct_devices"] = len({(r_["device"], r_["device_uuid_word"]) for r_ in ranks_seen})
+        if world == 1 and not args.no_projection:
+            try:
+                out["projected_scaling"] = projected_scaling(p, ms_per_step, args.steps, dist_wm_ok)
+                chk = p.finalize([p.partial()])   # the key is whole again (rebind undone): same proof as before
+                out["projected_scaling"]["headline_proof_unchanged_after"] = bool((chk == proof).all())
+            except Exception as e:  # noqa: BLE001
+                out["projected_scaling"] = {"error": repr(e)}
         if world == 1 and not args.no_pipelined:
             try:
                 out["pipelined"] = pipelined_throughput(p, local_rank, max(args.steps, 10), proof)

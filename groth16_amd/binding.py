@@ -79,6 +79,19 @@ class DiagC(C.Structure):
                 ("mads_per_product", C.c_double), ("limbs", C.c_int)]
 
 
+class PkInfoC(C.Structure):
+    _fields_ = [("window_bits_z", C.c_int), ("window_bits_h", C.c_int), ("table_fallback", C.c_int), ("bucket_shard_rank", C.c_int),
+                ("bucket_shard_world", C.c_int), ("n_devices", C.c_int), ("device_bytes", C.c_uint64)]
+
+    FALLBACK = {0: "window tables", 1: "plain bases by request (G16_MSM_PRECOMP=0)", 2: "plain bases: a query is too long for merged entries",
+                3: "plain bases: the window tables did not fit in HBM (allocation failed or G16_PK_TABLE_BUDGET_MB)"}
+
+    def as_dict(self):
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_}
+        d["held_as"] = self.FALLBACK.get(int(self.table_fallback), "?")
+        return d
+
+
 class TimingsC(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_a_ms", "msm_b_g1_ms", "msm_b_g2_ms", "scalar_prep_ms", "finish_ms",
@@ -97,6 +110,7 @@ EXPORTS = [
     "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
     "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version", "g16_generate_parameters",
     "g16_host_qap_evaluations", "g16_serialized_point_size", "g16_serialize_points", "g16_deserialize_points",
+    "g16_pk_load_bucket_shard", "g16_pk_rebind_bucket_shard", "g16_pk_get_info", "g16_msm_bucket_shard", "g16_host_msm_model_shard",
 ]
 
 
@@ -149,6 +163,11 @@ class Lib:
         c.g16_pk_load.argtypes = [C.c_void_p, C.POINTER(PkViewC), C.POINTER(C.c_void_p)]
         c.g16_pk_free.argtypes = [C.c_void_p]
         c.g16_pk_free.restype = None
+        c.g16_pk_load_bucket_shard.argtypes = [C.c_void_p, C.POINTER(PkViewC), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        c.g16_pk_rebind_bucket_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        c.g16_pk_get_info.argtypes = [C.c_void_p, C.POINTER(PkInfoC)]
+        c.g16_msm_bucket_shard.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_uint64, C.c_int, C.c_int, u64p]
+        c.g16_host_msm_model_shard.argtypes = [C.c_int, C.c_int, u64p, u64p, C.c_uint64, C.c_int, C.c_int, C.c_int, u64p]
         c.g16_circuit_load.argtypes = [C.c_void_p, C.POINTER(CsrViewC), C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
         c.g16_circuit_free.argtypes = [C.c_void_p]
         c.g16_circuit_free.restype = None

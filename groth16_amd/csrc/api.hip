@@ -249,6 +249,52 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
     G16_DISPATCH(ctx->curve, I::pk_load(ctx, view, out));
 }
 
+// Bucket-space shard (round 5): the rank holds the WHOLE key as window tables and owns the buckets b mod world == rank of all five
+// MSMs; its g16_prove_partial[_h] then yields the partial sums over those buckets, and the ranks' records add up to the MSM sums in
+// g16_prove_finalize exactly like base-range shards' do.
+int g16_pk_load_bucket_shard(g16_ctx* ctx, const g16_pk_view* view, int rank, int world, g16_pk** out) {
+    if (!ctx || !view || !out || world < 1 || world > 64 || rank < 0 || rank >= world) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) return G16_ERR_BAD_ARG;   // per-device form only (one process per GPU)
+    if (world == 1) return g16_pk_load(ctx, view, out);
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    G16_DISPATCH(ctx->curve, I::pk_load(ctx, view, out, world, rank));
+}
+
+// the same resident tables seen as another rank's bucket-space shard (the tables do not depend on the rank): lets ONE GPU walk through
+// every rank's share of a sharded proof -- the parity tests at sizes where loading the key once per rank would dominate, and
+// bench.py --sim-shards
+int g16_pk_rebind_bucket_shard(g16_pk* pk, int rank, int world) {
+    if (!pk || world < 1 || world > 64 || rank < 0 || rank >= world || !pk->subs.empty() || !pk->dp) return G16_ERR_BAD_ARG;
+    auto rebind = [&](auto* dp) -> int {
+        if (dp->c_z == 0 || dp->a_start || dp->b_g1_start || dp->b_g2_start || dp->h_start || dp->l_start) return G16_ERR_BAD_ARG;
+        dp->shard_n = world;
+        dp->shard_r = rank;
+        return G16_OK;
+    };
+    if (pk->ctx->finprep.key_id == pk->id) pk->ctx->finprep.drop();
+    if (pk->curve == G16_BLS12_381) return rebind(static_cast<DevicePk<Bls12_381>*>(pk->dp));
+    return rebind(static_cast<DevicePk<Bn254>*>(pk->dp));
+}
+
+int g16_pk_get_info(const g16_pk* pk, g16_pk_info* out) {
+    if (!pk || !out) return G16_ERR_BAD_ARG;
+    memset(out, 0, sizeof(*out));
+    const g16_pk* one = pk->subs.empty() ? pk : pk->subs[0];
+    if (!one || !one->dp) return G16_ERR_BAD_ARG;
+    auto fill = [&](const auto* dp) {
+        out->window_bits_z = dp->c_z;
+        out->window_bits_h = dp->c_h;
+        out->table_fallback = dp->table_fallback;
+        out->bucket_shard_rank = dp->shard_r;
+        out->bucket_shard_world = dp->shard_n;
+        out->device_bytes = dp->table_bytes;
+    };
+    if (one->curve == G16_BLS12_381) fill(static_cast<const DevicePk<Bls12_381>*>(one->dp));
+    else fill(static_cast<const DevicePk<Bn254>*>(one->dp));
+    out->n_devices = pk->subs.empty() ? 1 : (int)pk->subs.size();
+    return G16_OK;
+}
+
 void g16_pk_free(g16_pk* pk) {
     if (!pk) return;
     if (!pk->ctx->subs.empty()) {
@@ -614,6 +660,15 @@ int g16_msm_g2(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uin
     G16_DISPATCH(ctx->curve, I::template msm_api<typename I::Fq2>(ctx, bases, scalars, n, out_affine));
 }
 
+int g16_msm_bucket_shard(g16_ctx* ctx, int g2, const uint64_t* bases, const uint64_t* scalars, uint64_t n, int rank, int world,
+                         uint64_t* out_affine) {
+    if (!ctx || !out_affine || (n && (!bases || !scalars)) || world < 1 || world > 64 || rank < 0 || rank >= world) return G16_ERR_BAD_ARG;
+    if (!ctx->subs.empty()) return g16_msm_bucket_shard(ctx->subs[0], g2, bases, scalars, n, rank, world, out_affine);
+    G16_HIP_TRY(hipSetDevice(ctx->device));
+    if (!g2) G16_DISPATCH(ctx->curve, I::template msm_api<typename I::Fq>(ctx, bases, scalars, n, out_affine, world, rank));
+    G16_DISPATCH(ctx->curve, I::template msm_api<typename I::Fq2>(ctx, bases, scalars, n, out_affine, world, rank));
+}
+
 int g16_ntt(g16_ctx* ctx, uint64_t* data, int log_n, int inverse, int coset) {
     if (!ctx || !data) return G16_ERR_BAD_ARG;
     if (!ctx->subs.empty()) return g16_ntt(ctx->subs[0], data, log_n, inverse, coset);
@@ -649,6 +704,13 @@ int g16_host_msm_model(int curve, int g2, const uint64_t* bases, const uint64_t*
     if (!out_affine || (n && (!bases || !scalars))) return G16_ERR_BAD_ARG;
     if (!g2) G16_DISPATCH(curve, I::template msm_model<typename I::Fq>(bases, scalars, n, c, out_affine));
     G16_DISPATCH(curve, I::template msm_model<typename I::Fq2>(bases, scalars, n, c, out_affine));
+}
+
+int g16_host_msm_model_shard(int curve, int g2, const uint64_t* bases, const uint64_t* scalars, uint64_t n, int c, int rank, int world,
+                             uint64_t* out_affine) {
+    if (!out_affine || (n && (!bases || !scalars)) || world < 1 || world > 64 || rank < 0 || rank >= world) return G16_ERR_BAD_ARG;
+    if (!g2) G16_DISPATCH(curve, I::template msm_model<typename I::Fq>(bases, scalars, n, c, out_affine, world, rank));
+    G16_DISPATCH(curve, I::template msm_model<typename I::Fq2>(bases, scalars, n, c, out_affine, world, rank));
 }
 
 int g16_generate_parameters(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints, uint64_t num_variables,

@@ -212,6 +212,14 @@ struct DevicePk {
     // `count` points, row j = 2^(cj) * query.  0 = no tables (plain bases, per-window buckets).  a, b_g1, b_g2 and l share
     // the witness sort and therefore one window size; h has its own.
     int c_z = 0, c_h = 0;
+    // bucket-space shard (g16_pk_load_bucket_shard): the key is held WHOLE and this rank owns the buckets b mod shard_n == shard_r of
+    // every MSM (MsmPlan::shard_n); 1 = the key (or base-range shard) is proved over all its buckets
+    int shard_n = 1, shard_r = 0;
+    // why the key is held the way it is (g16_pk_info): 0 window tables as planned; 1 plain bases by request (G16_MSM_PRECOMP=0);
+    // 2 plain bases because a query is too long for merged entries; 3 plain bases because the tables did not fit (allocation failed
+    // or G16_PK_TABLE_BUDGET_MB) -- a slower prover (c <= 16, more windows), which the caller can now see
+    int table_fallback = 0;
+    uint64_t table_bytes = 0;   // device bytes of the five query arrays as held
 };
 
 // every key handle gets a fresh id: a prepared finalize half is matched by id, never by the handle's address (a freed key's

@@ -180,6 +180,12 @@ struct MsmPlan {
     int affine_levels = 0;
     uint32_t chunk = 0; // points per histogram/scatter block
     uint32_t K[10];     // signed-digit bias  sum_w 2^(c-1) 2^(cw)
+    // BUCKET-SPACE SHARD of a merged plan (round 5; one rank of shard_n, every rank holding the WHOLE window table): the rank owns
+    // the buckets b with b mod shard_n == shard_r and indexes them locally by k = b / shard_n, so its sort keeps only the entries of
+    // that residue class, its bucket pass folds ~1/shard_n of them, and -- unlike a shard of the BASES, which leaves every rank all
+    // 2^(c-1) buckets -- its reductions shrink shard_n-fold too.  groups * B >= ceil(2^(c-1) / shard_n) local buckets; fold_windows
+    // turns the local sums into the rank's share  sum_{b owned} (b+1) S_b = shard_n sum_k (k+1) S_k + (shard_r + 1 - shard_n) sum_k S_k.
+    int shard_n = 1, shard_r = 0;
     uint32_t buckets() const { return B * (uint32_t)groups; }
     // Reduction of one group of B buckets: chunks of min(G, B) buckets per lane give (sum_b (b - b_lo + 1) S_b, sum_b S_b);
     // the chunk offsets b_lo = G * ch are applied WITHOUT a scalar multiplication in the dependent chain: the window level
@@ -196,7 +202,9 @@ static constexpr int MSM_MAX_OUTPUTS = 256;
 static constexpr int MSM_MERGED_MIN_C = 9, MSM_MERGED_MAX_C = 20;   // merged entries pack window j < 32 and point i < 2^26
 static constexpr uint64_t MSM_MERGED_MAX_N = (uint64_t)1 << 26;
 // merged_c = 0: per-window plan, window size from the cost model (or G16_MSM_WINDOW); else a merged plan with that c
-int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, int merged_c, MsmPlan* plan);
+// shard_n > 1 (merged plans only): the plan of rank shard_r's bucket-space shard (MsmPlan::shard_n)
+int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, int merged_c, MsmPlan* plan, int shard_n = 1,
+                  int shard_r = 0);
 int msm_window_override();  // env G16_MSM_WINDOW (0 = auto)
 // window size for the precomputed tables of a query with n bases (0 = no tables: disabled by G16_MSM_PRECOMP=0 or n too large)
 int merged_window_bits(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords);
@@ -214,7 +222,8 @@ struct ScalarSort {
     uint32_t max_segments = 0;     // host-side upper bound on ceil(entries the bucket pass walks / Lmax)
     uint64_t max_sorted = 0;       // host-side upper bound on offsets[buckets]: entries + padding of the batched-affine plan
 };
-template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Arena& arena, hipStream_t st, ScalarSort* out);
+template <class C> int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Arena& arena, hipStream_t st, ScalarSort* out,
+                                    int shard_n = 1, int shard_r = 0);
 
 // Pippenger over one base array using a ScalarSort, in two stream-separable halves:
 //   msm_bucket_pass  the throughput-bound bucket accumulation.  Sorted index p addresses bases[p + shift] when

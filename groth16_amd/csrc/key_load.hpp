@@ -117,7 +117,9 @@ struct KeyLoader {
         delete p;
     }
 
-    static int pk_load(g16_ctx* ctx, const g16_pk_view* v, g16_pk** out) {
+    // shard_n > 1: bucket-space shard `shard_r` of `shard_n` -- the view must be the WHOLE key, and the key must get its window
+    // tables (merged plans only; there is no silent fall-back to plain bases in this mode: G16_ERR_OOM instead)
+    static int pk_load(g16_ctx* ctx, const g16_pk_view* v, g16_pk** out, int shard_n = 1, int shard_r = 0) {
         if (!v->alpha_g1 || !v->beta_g1 || !v->delta_g1 || !v->beta_g2 || !v->delta_g2 || !v->a_query0 || !v->b_g1_query0 ||
             !v->b_g2_query0)
             return G16_ERR_BAD_ARG;
@@ -149,7 +151,25 @@ struct KeyLoader {
         p->c_h = merged_window_bits(v->h.count, Fr::Params::BITS, modw, Fr::N);
         if (v->h.count == 0) p->c_h = p->c_z;
         if (nz == 0) p->c_z = p->c_h;
-        if (p->c_z == 0 || p->c_h == 0) p->c_z = p->c_h = 0;   // tables for all queries or for none
+        if (p->c_z == 0 || p->c_h == 0) {   // tables for all queries or for none
+            const char* e = getenv("G16_MSM_PRECOMP");
+            p->table_fallback = (nz || v->h.count) ? ((e && atoi(e) == 0) ? 1 : 2) : 0;
+            p->c_z = p->c_h = 0;
+        }
+        p->shard_n = shard_n;
+        p->shard_r = shard_r;
+        if (shard_n > 1) {
+            if (v->a.start || v->b_g1.start || v->b_g2.start || v->h.start || v->l.start) {
+                delete p;
+                g_last_error = "a bucket-space shard is loaded from the WHOLE key (every query.start == 0): the ranks divide the buckets, not the bases";
+                return G16_ERR_BAD_ARG;
+            }
+            if (p->c_z == 0) {
+                delete p;
+                g_last_error = "a bucket-space shard needs the key's window tables (merged windows): G16_MSM_PRECOMP=0 or an over-long query rules them out";
+                return G16_ERR_BAD_ARG;
+            }
+        }
         LoadScratch ls;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const int cz = p->c_z, ch = p->c_h;
@@ -162,11 +182,14 @@ struct KeyLoader {
                 (void)hipFree(p->a); (void)hipFree(p->b_g1); (void)hipFree(p->b_g2); (void)hipFree(p->h); (void)hipFree(p->l);
                 p->a = p->b_g1 = p->h = p->l = nullptr;
                 p->b_g2 = nullptr;
-                if (rc == G16_ERR_OOM && cz != 0) {   // the tables do not fit next to what already lives on this GPU: plain bases
+                if (rc == G16_ERR_OOM && cz != 0 && shard_n <= 1) {   // the tables do not fit next to what already lives on this GPU: plain bases
                     (void)hipGetLastError();
                     p->c_z = p->c_h = 0;
+                    p->table_fallback = 3;
                     continue;
                 }
+                if (rc == G16_ERR_OOM && shard_n > 1)
+                    g_last_error = "the whole key's window tables do not fit on this GPU: a bucket-space shard cannot be held (use base-range shards)";
                 pk_free(p);
                 return rc;
             }
@@ -177,6 +200,12 @@ struct KeyLoader {
         p->b_g2_start = v->b_g2.start; p->b_g2_count = v->b_g2.count;
         p->h_start = v->h.start; p->h_count = v->h.count;
         p->l_start = v->l.start; p->l_count = v->l.count;
+        {
+            const uint64_t rows_z = p->c_z ? (uint64_t)msm_plan_windows(p->c_z, Fr::Params::BITS, modw, Fr::N) : 1;
+            const uint64_t rows_h = p->c_h ? (uint64_t)msm_plan_windows(p->c_h, Fr::Params::BITS, modw, Fr::N) : 1;
+            p->table_bytes = rows_z * ((v->a.count + v->b_g1.count + v->l.count) * sizeof(G1A) + v->b_g2.count * sizeof(G2A)) +
+                             rows_h * v->h.count * sizeof(G1A);
+        }
         const bool load_ok = hipStreamSynchronize(ctx->stream) == hipSuccess;   // every table is built: the load-time scratch can go
         ls.release();
         if (!load_ok) { pk_free(p); return G16_ERR_HIP; }

@@ -64,7 +64,20 @@ struct PlanDev {
     int c, W;
     uint32_t B;
     uint32_t K[10];
+    // bucket-space shard (MsmPlan::shard_n): keep the keys with key mod shard_n == shard_r, re-index them as key / shard_n.
+    // shard_magic = ceil(2^32 / shard_n): umulhi(key, magic) == key / shard_n exactly for key < 2^20, shard_n <= 64
+    // (key * (magic * shard_n - 2^32) < 2^20 * 64 < 2^32).  shard_n == 1: no filter.
+    uint32_t shard_n, shard_r, shard_magic;
 };
+
+// false: the key belongs to another rank's residue class; true: *key is now the rank's local bucket index
+__device__ __forceinline__ bool shard_local_key(const PlanDev& plan, uint32_t* key) {
+    if (plan.shard_n <= 1) return true;
+    const uint32_t q = __umulhi(*key, plan.shard_magic);
+    if (*key - q * plan.shard_n != plan.shard_r) return false;
+    *key = q;
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------
 // 1. digit planes
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(CLASS_THREADS) void class_count_kernel(const Fr* __
         biased_scalar(scalars[i], plan, sw);
         for (int w = 0; w < plan.W; ++w) {
             uint32_t key, neg;
-            if (digit_to_bucket(window_of(sw, w, plan.c), plan.c, &key, &neg)) atomicAdd(&cnt[key >> blog], 1u);
+            if (digit_to_bucket(window_of(sw, w, plan.c), plan.c, &key, &neg) && shard_local_key(plan, &key)) atomicAdd(&cnt[key >> blog], 1u);
         }
     }
     __syncthreads();
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(CLASS_THREADS) void class_partition_kernel(const Fr
     biased_scalar(scalars[i], plan, sw);
     for (int w = 0; w < plan.W; ++w) {
         uint32_t key, neg;
-        if (digit_to_bucket(window_of(sw, w, plan.c), plan.c, &key, &neg)) {
+        if (digit_to_bucket(window_of(sw, w, plan.c), plan.c, &key, &neg) && shard_local_key(plan, &key)) {
             const uint32_t pos = atomicAdd(&cur[key >> blog], 1u);
             ent_key[pos] = (uint16_t)((key & ((1u << blog) - 1u)) | (neg << 15));
             ent_tag[pos] = (uint32_t)i | ((uint32_t)w << 26);
@@ -843,7 +856,9 @@ int merged_window_bits(uint64_t n, int scalar_bits, const uint32_t* modulus_word
     return (W < 0 || W > 32) ? 0 : c;
 }
 
-int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, int merged_c, MsmPlan* plan) {
+int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, int mod_nwords, int merged_c, MsmPlan* plan, int shard_n,
+                  int shard_r) {
+    if (shard_n < 1 || shard_n > 64 || shard_r < 0 || shard_r >= shard_n || (shard_n > 1 && merged_c <= 0)) return G16_ERR_INTERNAL;
     int c = merged_c;
     if (c <= 0) {
         c = msm_window_override();
@@ -866,9 +881,16 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
     plan->c = c;
     plan->W = W;
     plan->merged = merged_c > 0;
+    plan->shard_n = shard_n;
+    plan->shard_r = shard_r;
     if (plan->merged) {
-        plan->B = 1u << (c > 16 ? 15 : c - 1);
-        plan->groups = c > 16 ? 1 << (c - 16) : 1;
+        // classes of B <= 2^15 buckets (what the LDS histogram holds) over the rank's buckets: all 2^(c-1) of them, or -- bucket-space
+        // shard -- the ceil(2^(c-1) / shard_n) local ones (bucket shard_n k + shard_r has local index k)
+        const uint32_t all = 1u << (c - 1), local = (all + (uint32_t)shard_n - 1) / (uint32_t)shard_n;
+        uint32_t B = 1;
+        while (B < local && B < (1u << 15)) B <<= 1;
+        plan->B = B;
+        plan->groups = (int)((local + B - 1) / B);
     } else {
         plan->B = 1u << (c - 1);
         plan->groups = W;
@@ -881,7 +903,8 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16 || v == 32) plan->G = (uint32_t)v;
     }
-    const uint64_t all_entries = n * (uint64_t)W;
+    const uint64_t all_entries = n * (uint64_t)W / (uint64_t)shard_n;   // EXPECTED entries of this rank (uniform digits); buffers
+                                                                          // are sized for the worst case in sort_scalars
     // batched-affine levels: they pay when buckets are long (each level halves a bucket's entries at ~0.6 of the XYZZ cost
     // per addition, but a lane needs >= ~16 pairs to amortise its inversion and the chip >= ~2 k waves to stay busy)
     plan->affine_levels = 0;
@@ -898,6 +921,7 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
             if (v >= 0 && v <= 4) R = v;
         }
         if (all_entries + (uint64_t)plan->buckets() * ((1u << R) - 1u) >= ((uint64_t)1 << 32)) R = 0;
+        if (shard_n > 1) R = 0;   // (an experiment that is off by default: not carried into the bucket-space shard)
         plan->affine_levels = R;
     }
     const uint64_t entries = (all_entries >> plan->affine_levels) + (plan->affine_levels ? plan->buckets() : 0);   // what the bucket pass walks
@@ -933,13 +957,14 @@ int make_msm_plan(uint64_t n, int scalar_bits, const uint32_t* modulus_words, in
 static int ilog2(uint32_t v) { int l = 0; while ((1u << l) < v) ++l; return l; }
 
 template <class C>
-int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Arena& arena, hipStream_t st, ScalarSort* out) {
+int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Arena& arena, hipStream_t st, ScalarSort* out, int shard_n,
+                 int shard_r) {
     typedef typename C::Fr Fr;
     if (n >= ((uint64_t)1 << 31)) return G16_ERR_BAD_LENGTH;
     uint32_t modw[Fr::N];
     for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
     MsmPlan plan;
-    G16_TRY(make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, merged_c, &plan));
+    G16_TRY(make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, merged_c, &plan, shard_n, shard_r));
     out->plan = plan;
     out->n = n;
     const uint32_t M = plan.buckets();
@@ -979,6 +1004,9 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     PlanDev pd;
     pd.c = plan.c; pd.W = plan.W; pd.B = plan.B;
     for (int k = 0; k < 10; ++k) pd.K[k] = plan.K[k];
+    pd.shard_n = (uint32_t)plan.shard_n;
+    pd.shard_r = (uint32_t)plan.shard_r;
+    pd.shard_magic = plan.shard_n > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)plan.shard_n - 1) / (uint64_t)plan.shard_n) : 0u;
     const size_t lds = (size_t)plan.B * sizeof(uint32_t);
     static PerDeviceOnce attr_once;
     std::atomic<bool>& attr_set = attr_once.flag();
@@ -1225,6 +1253,15 @@ XYZZ<F> fold_windows(const XYZZ<F>* ws, const MsmPlan& plan) {
             for (uint32_t b = plan.B; b > 1; b >>= 1) total = total.dbl();
         }
         for (int q = 0; q < Q; ++q) total.add(group_T(q));
+        if (plan.shard_n > 1) {
+            // bucket-space shard: `total` is sum_k (k+1) S_k over the LOCAL indices; the rank's buckets are b = shard_n k + shard_r, so its
+            // share of the MSM is  shard_n * total - (shard_n - 1 - shard_r) * sum_k S_k   (two multiplications by numbers below 64)
+            XYZZ<F> plain = XYZZ<F>::identity();
+            for (int q = 0; q < Q; ++q) plain.add(ws[(size_t)q * NP + 1]);
+            const uint32_t kn = (uint32_t)plan.shard_n, km = (uint32_t)(plan.shard_n - 1 - plan.shard_r);
+            total = total.mul_bits(&kn, 7);
+            if (km) total.add(plain.mul_bits(&km, 7).neg());
+        }
         return total;
     }
     for (int w = plan.W - 1; w >= 0; --w) {
@@ -1291,7 +1328,7 @@ int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine
 #define G16_INSTANTIATE_MSM(C)                                                                                               \
     template int convert_bases<typename C::Fq>(Affine<typename C::Fq>*, uint64_t, hipStream_t);                             \
     template int convert_bases<typename C::Fq2>(Affine<typename C::Fq2>*, uint64_t, hipStream_t);                           \
-    template int sort_scalars<C>(const typename C::Fr*, uint64_t, int, Arena&, hipStream_t, ScalarSort*);                   \
+    template int sort_scalars<C>(const typename C::Fr*, uint64_t, int, Arena&, hipStream_t, ScalarSort*, int, int);                   \
     template int build_window_tables<typename C::Fq>(const Affine<typename C::Fq>*, uint64_t, int, int, Affine<typename C::Fq>*, hipStream_t, void*);    \
     template int build_window_tables<typename C::Fq2>(const Affine<typename C::Fq2>*, uint64_t, int, int, Affine<typename C::Fq2>*, hipStream_t, void*); \
     template size_t window_table_park_bytes<typename C::Fq>(uint64_t, int);                                                 \

@@ -37,7 +37,7 @@ struct Prover {
         ctx->reset_arena();
         const Fr* d_z = reinterpret_cast<const Fr*>(z_dev);
         ScalarSort ss;
-        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, ctx->stream2, &ss)));
+        G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, ctx->stream2, &ss, pk->shard_n, pk->shard_r)));
         G16_HIP_TRY(hipEventRecord(ctx->ev_z, ctx->stream2));
         ctx->prep.valid = true;
         ctx->prep.pk = pkh;
@@ -111,7 +111,7 @@ struct Prover {
         } else {
             G16_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_z, 0));
             G16_TRY(ctx->t_prep_z.start(s2));
-            G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, s2, &sort_z)));
+            G16_TRY((sort_scalars<C>(d_z + 1 + pk->a_start, pk->a_count, pk->c_z, ctx->arena, s2, &sort_z, pk->shard_n, pk->shard_r)));
             G16_TRY(ctx->t_prep_z.stop(s2));
             G16_HIP_TRY(hipEventRecord(ctx->ev_z, s2));   // (re-recorded: now also covers the witness sort)
         }
@@ -119,7 +119,7 @@ struct Prover {
         // ---- stream 3: h's digit/sort pass, underneath the first bucket pass (stream 2 stays free for the reductions)
         G16_HIP_TRY(hipStreamWaitEvent(s3, ctx->ev_wm, 0));
         G16_TRY(ctx->t_prep_h.start(s3));
-        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, pk->c_h, ctx->arena, s3, &sort_h)));
+        G16_TRY((sort_scalars<C>(d_h + pk->h_start, pk->h_count, pk->c_h, ctx->arena, s3, &sort_h, pk->shard_n, pk->shard_r)));
         G16_TRY(ctx->t_prep_h.stop(s3));
         G16_HIP_TRY(hipEventRecord(ctx->ev_h, s3));
 
@@ -139,7 +139,7 @@ struct Prover {
         // pass -- a reduction is a few hundred waves of dependent additions that hold register slots for milliseconds and slowed
         // every pass they ran under (8-way shard at 2^22: 1.8-2.1 ms per pass instead of 1.2) -- but run TOGETHER, one launch per
         // stage for all of them (msm_reduce_batch), after the last pass: 4x the waves per launch, one chain of latency instead of four.
-        const bool short_passes = (uint64_t)pk->a_count * (uint64_t)sort_z.plan.W < 20000000ull;
+        const bool short_passes = (uint64_t)pk->a_count * (uint64_t)sort_z.plan.W / (uint64_t)pk->shard_n < 20000000ull;
         // Timestamps: ONE event per boundary between back-to-back passes (the end of pass k is the begin of pass k + 1) instead of a
         // start / stop / done / span-start record around every pass -- each record is a barrier packet the command processor retires
         // before it starts the next kernel, and the four of them cost ~0.13 ms of idle GPU between two passes (kernel trace of round 3).
@@ -193,7 +193,7 @@ struct Prover {
             G16_TRY(heavy_early(1, buf_l, sort_z));
             jobs[njobs++] = {1, &buf_l, &sort_z};
         } else {
-            G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, pk->c_z, ctx->arena, s1, &sort_l)));
+            G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, pk->c_z, ctx->arena, s1, &sort_l, pk->shard_n, pk->shard_r)));
             last_end = nullptr;   // the sort sits between the passes: this one gets its own begin mark
             G16_TRY(run_pass(1, pk->l, 0, pk->l_count, sort_l, &buf_l));
             G16_TRY(heavy_early(1, buf_l, sort_l));

@@ -58,8 +58,11 @@ struct UnitApi {
         return G16_OK;
     }
 
+    // shard_n > 1: rank shard_r's bucket-space share of the MSM (window tables built on the fly, merged windows): the ranks' results
+    // add up to the MSM
     template <class F>
-    static int msm_api(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine) {
+    static int msm_api(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine, int shard_n = 1,
+                       int shard_r = 0) {
         typedef Affine<F> A;
         typedef XYZZ<F> X;
         hipStream_t st = ctx->stream;
@@ -79,7 +82,9 @@ struct UnitApi {
         const char* e = getenv("G16_MSM_API_PRECOMP");
         uint32_t modw[Fr::N];
         for (int i = 0; i < Fr::N; ++i) modw[i] = Fr::Params::mod(i);
-        if (e && atoi(e) != 0 && n) merged_c = merged_window_bits(n, Fr::Params::BITS, modw, Fr::N);
+        if (((e && atoi(e) != 0) || shard_n > 1) && n) merged_c = merged_window_bits(n, Fr::Params::BITS, modw, Fr::N);
+        if (shard_n > 1 && n && !merged_c) return G16_ERR_BAD_ARG;   // G16_MSM_PRECOMP=0 / too many points for merged entries
+        if (shard_n > 1 && !n) { memset(out_affine, 0, sizeof(A)); drain.dismiss(); return G16_OK; }
         if (merged_c) {
             const int W = msm_plan_windows(merged_c, Fr::Params::BITS, modw, Fr::N);
             A* d_t = nullptr;
@@ -90,7 +95,7 @@ struct UnitApi {
             G16_TRY((convert_bases<F>(d_b, n, st)));
         }
         ScalarSort ss;
-        G16_TRY((sort_scalars<C>(d_s, n, merged_c, ctx->arena, st, &ss)));
+        G16_TRY((sort_scalars<C>(d_s, n, merged_c, ctx->arena, st, &ss, shard_n, shard_r)));
         MsmBuffers<F> buf;
         G16_TRY((msm_bucket_pass<F>(d_b, 0, n, ss, ctx->arena, st, &buf, &ctx->t_bucket[0])));
         G16_TRY((msm_reduce<F>(buf, ss, st)));
@@ -190,8 +195,10 @@ struct UnitApi {
     // CPU model of kernels 1-7 of msm.hip: same plan, same digit/bucket/sign mapping, same chunked running-sum reduction
     // and final fold.  c_override > 0: per-window plan with that window size; < 0: merged plan with window size -c_override
     // (window tables 2^(cj) P_i built here by repeated doubling); 0: per-window plan from the cost model.
+    // shard_n > 1 (merged plans): rank shard_r's bucket-space share, exactly as sort_scalars filters and re-indexes the keys
     template <class F>
-    static int msm_model(const uint64_t* bases_, const uint64_t* scalars_, uint64_t n, int c_override, uint64_t* out) {
+    static int msm_model(const uint64_t* bases_, const uint64_t* scalars_, uint64_t n, int c_override, uint64_t* out, int shard_n = 1,
+                         int shard_r = 0) {
         typedef Affine<F> A;
         typedef XYZZ<F> X;
         uint32_t modw[Fr::N];
@@ -202,7 +209,8 @@ struct UnitApi {
             snprintf(buf, sizeof(buf), "%d", c_override);
             setenv("G16_MSM_WINDOW", buf, 1);
         }
-        int rc = make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, c_override < 0 ? -c_override : 0, &plan);
+        if (shard_n > 1 && c_override >= 0) return G16_ERR_BAD_ARG;
+        int rc = make_msm_plan(n, Fr::Params::BITS, modw, Fr::N, c_override < 0 ? -c_override : 0, &plan, shard_n, shard_r);
         if (c_override > 0) unsetenv("G16_MSM_WINDOW");
         if (rc) return rc;
         const A* bases = reinterpret_cast<const A*>(bases_);
@@ -229,6 +237,10 @@ struct UnitApi {
                 }
                 uint32_t bucket, neg;
                 if (!digit_to_bucket(window_raw(sp, w, plan.c), plan.c, &bucket, &neg)) continue;
+                if (plan.shard_n > 1) {
+                    if (bucket % (uint32_t)plan.shard_n != (uint32_t)plan.shard_r) continue;   // another rank's residue class
+                    bucket /= (uint32_t)plan.shard_n;                                            // local index k: b = shard_n k + shard_r
+                }
                 A q = p;
                 if (neg) q.y = q.y.neg();
                 // merged: `bucket` is the key over all 2^(c-1) buckets = group * B + bucket-in-group already

@@ -13,8 +13,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .binding import (CURVE_ID, FQ_LIMBS, CsrViewC, ParamsViewC, PartialC, PkViewC, ProofC, QueryC, TimingsC, ToxicWasteC, lib, ptr32,
-                      ptr64, u64p)
+from .binding import (CURVE_ID, FQ_LIMBS, CsrViewC, ParamsViewC, PartialC, PkInfoC, PkViewC, ProofC, QueryC, TimingsC, ToxicWasteC, lib,
+                      ptr32, ptr64, u64p)
 
 _MODULUS_R = {
     "bls12_381": 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
@@ -160,20 +160,25 @@ class _Ctx:
 
 
 class _DevicePk:
-    """g16_pk handle; shard = (index, count) splits every MSM base array into contiguous ranges."""
+    """g16_pk handle.  shard = (index, count) splits every MSM base array into contiguous ranges (base-range shards);
+    shard = (index, count, "bucket") is the bucket-space shard: the whole key on every rank, rank `index` owning the buckets
+    b mod count == index (g16_pk_load_bucket_shard)."""
 
-    def __init__(self, ctx: _Ctx, pk: ProvingKey, num_inputs: int, shard: Tuple[int, int] = (0, 1), dist_h: bool = False):
+    def __init__(self, ctx: _Ctx, pk: ProvingKey, num_inputs: int, shard=(0, 1), dist_h: bool = False):
         """dist_h: the h_query shard is this rank's block of the distributed witness map (dist_h_indices) instead of a
-        contiguous range -- the form g16_prove_partial_h expects"""
+        contiguous range -- the form g16_prove_partial_h expects; bucket-space shard: the WHOLE h_query in the order the
+        all-gathered blocks arrive in (bucket_h_indices)"""
         self.ctx = ctx
         self.handle = C.c_void_p()
         self._keep = []
-        idx, cnt = shard
-        rg = shard_ranges(len(pk.a_query) - 1, len(pk.l_query), len(pk.h_query), num_inputs, idx, cnt)
+        idx, cnt = shard[0], shard[1]
+        bucket = len(shard) > 2 and shard[2] == "bucket"
+        rg = shard_ranges(len(pk.a_query) - 1, len(pk.l_query), len(pk.h_query), num_inputs, 0 if bucket else idx, 1 if bucket else cnt)
         (a_lo, a_hi), (l_lo, l_hi), (h_lo, h_hi) = rg["a"], rg["l"], rg["h"]
         h_query = pk.h_query
         if dist_h:
-            sel = dist_h_indices(len(pk.h_query) + 1, idx, cnt)       # domain size n = len(h_query) + 1 (generator.rs:168)
+            n_dom = len(pk.h_query) + 1                                  # domain size n = len(h_query) + 1 (generator.rs:168)
+            sel = bucket_h_indices(n_dom, cnt) if bucket else dist_h_indices(n_dom, idx, cnt)
             h_query = pk.h_query[sel[sel < len(pk.h_query)]]            # only the very last index of the last rank is n - 1
             h_lo, h_hi = 0, len(h_query)
 
@@ -187,8 +192,21 @@ class _DevicePk:
         self._keep += keep
         view = PkViewC(*[ptr64(k) for k in keep], q(pk.a_query, 1, a_lo, a_hi), q(pk.b_g1_query, 1, a_lo, a_hi),
                        q(pk.b_g2_query, 1, a_lo, a_hi), q(h_query, 0, h_lo, h_hi), q(pk.l_query, 0, l_lo, l_hi), 0)
-        ctx.lib.check(ctx.lib.c.g16_pk_load(ctx.handle, C.byref(view), C.byref(self.handle)))
+        if bucket:
+            ctx.lib.check(ctx.lib.c.g16_pk_load_bucket_shard(ctx.handle, C.byref(view), idx, cnt, C.byref(self.handle)))
+        else:
+            ctx.lib.check(ctx.lib.c.g16_pk_load(ctx.handle, C.byref(view), C.byref(self.handle)))
         self._keep = []  # the library copied everything
+
+    def rebind(self, rank: int, world: int):
+        """g16_pk_rebind_bucket_shard: the same resident tables as rank `rank` of `world` (tests, --sim-shards)"""
+        self.ctx.lib.check(self.ctx.lib.c.g16_pk_rebind_bucket_shard(self.handle, rank, world))
+
+    def info(self) -> dict:
+        """g16_pk_get_info: window sizes, why the key is held as plain bases if it is, bucket-shard rank / world, HBM bytes"""
+        out = PkInfoC()
+        self.ctx.lib.check(self.ctx.lib.c.g16_pk_get_info(self.handle, C.byref(out)))
+        return out.as_dict()
 
     def close(self):
         if self.handle:
@@ -202,6 +220,13 @@ def dist_h_indices(n: int, rank: int, world: int) -> np.ndarray:
     M = n // world
     blk = M // world
     return ((rank * blk + np.arange(blk, dtype=np.int64))[None, :] + (M * np.arange(world, dtype=np.int64))[:, None]).reshape(-1)
+
+
+def bucket_h_indices(n: int, world: int) -> np.ndarray:
+    """h coefficients in the order an all-gather of the ranks' blocks of the distributed witness map leaves them in: rank 0's
+    block (dist_h_indices), rank 1's, ... -- the order a bucket-space shard's h_query is loaded in, since there every rank
+    runs the h MSM over ALL coefficients (and 1 / world of the buckets)"""
+    return np.concatenate([dist_h_indices(n, q, world) for q in range(world)])
 
 
 def _csr_views(m: "ConstraintMatrices"):
@@ -496,6 +521,16 @@ class Groth16:
         lb.check(fn(self._ctx.handle, ptr64(b) if n else None, ptr64(s) if n else None, n, ptr64(out)))
         return out
 
+    def msm_bucket_shard(self, bases: np.ndarray, scalars: np.ndarray, rank: int, world: int, g2: bool = False) -> np.ndarray:
+        """g16_msm_bucket_shard: rank's bucket-space share of msm(bases, scalars) -- the `world` results add up to the MSM"""
+        L = FQ_LIMBS[self.curve]
+        n = min(len(bases), len(scalars))
+        b, s = _c(bases[:n]), _c(scalars[:n])
+        out = np.zeros((4 if g2 else 2) * L, dtype=np.uint64)
+        lb = self._ctx.lib
+        lb.check(lb.c.g16_msm_bucket_shard(self._ctx.handle, int(g2), ptr64(b) if n else None, ptr64(s) if n else None, n, rank, world, ptr64(out)))
+        return out
+
     # -- EvaluationDomain::{fft, ifft, coset variants}, natural order ---------------------------
     def ntt(self, data: np.ndarray, inverse: bool = False, coset: bool = False) -> np.ndarray:
         d = _c(data).copy()
@@ -506,6 +541,10 @@ class Groth16:
         lb = self._ctx.lib
         lb.check(lb.c.g16_ntt(self._ctx.handle, ptr64(d), log_n, int(inverse), int(coset)))
         return d
+
+    def pk_info(self, pk: ProvingKey, num_inputs: int, shard=(0, 1), dist_h: bool = False) -> dict:
+        """how the device-resident copy of (this shard of) the key is held: g16_pk_get_info"""
+        return self._pk(pk, num_inputs, shard, dist_h).info()
 
     def timings(self) -> dict:
         t = TimingsC()
@@ -630,6 +669,7 @@ class DistributedWitnessMap:
         self.blk = self.M // world
         mk = lambda: torch.empty((self.M, 4), dtype=torch.int64, device=device)  # noqa: E731
         self.work, self.recv, self.h_local = [mk() for _ in range(3)], [mk() for _ in range(3)], mk()
+        self.h_full = None   # all_gather_h: the n-element buffer of a bucket-space shard
         self._wp = (C.c_void_p * 3)(*[t.data_ptr() for t in self.work])
         self._rp = (C.c_void_p * 3)(*[t.data_ptr() for t in self.recv])
 
@@ -695,10 +735,40 @@ class DistributedWitnessMap:
                 torch.cuda.synchronize()   # the next stage runs on the library's own stream
         return self.h_local
 
+    def all_gather_h(self, dist=None, simulate: bool = False):
+        """h WHOLE on this rank, for a bucket-space shard (every rank runs the h MSM over all coefficients and 1 / world of the
+        buckets): ONE all-gather of the ranks' blocks (n / world Fr each -- 16 MiB per rank at 2^22 / 8) into an n-element buffer, in
+        rank order -- the order `bucket_h_indices` lists and the key's h_query is loaded in, so nothing is un-permuted.  With RCCL
+        (or one rank, or `simulate`: this rank's block copied `world` times -- the same bytes written, for the one-GPU share
+        measurement) the gather is enqueued on the witness-map stream behind the map's last stage, with no host synchronisation;
+        a following prove_partial_h orders itself after that stream.  gloo (tests): through the host."""
+        import torch
+
+        if getattr(self, "h_full", None) is None:
+            self.h_full = torch.empty((self.M * self.world, 4), dtype=torch.int64, device=self.h_local.device)
+        multi = dist is not None and self.world > 1 and not simulate
+        if multi and dist.get_backend() != "nccl":
+            torch.cuda.synchronize()
+            mine = self.h_local.cpu()
+            every = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(every, mine)
+            self.h_full.copy_(torch.cat(every))
+            torch.cuda.synchronize()
+            return self.h_full
+        ext = torch.cuda.ExternalStream(int(self.lib.c.g16_ctx_wm_stream(self.ctx)), device=self.h_local.device)
+        with torch.cuda.stream(ext):
+            if multi:
+                dist.all_gather_into_tensor(self.h_full, self.h_local)
+            else:
+                for q in range(self.world):
+                    self.h_full[q * self.M:(q + 1) * self.M].copy_(self.h_local, non_blocking=True)
+        return self.h_full
+
     def close(self):
         if self.handle:
             self.lib.c.g16_dwm_free(self.handle)
             self.handle = C.c_void_p()
+        self.h_full = None
 
 
 class PipelinedProver:
@@ -771,13 +841,18 @@ class ShardedProver:
 
     PARTIAL_BYTES = C.sizeof(PartialC)
 
-    def __init__(self, prover: Groth16, pk: ProvingKey, matrices: ConstraintMatrices, rank: int, world_size: int):
+    def __init__(self, prover: Groth16, pk: ProvingKey, matrices: ConstraintMatrices, rank: int, world_size: int, mode: str = "base"):
+        """mode "base": contiguous ranges of the bases per rank (1 / world of the key's memory per GPU); "bucket": the whole key
+        on every GPU, the BUCKETS divided (b mod world == rank) -- the bucket reductions then shrink with the rank count too
+        (g16_pk_load_bucket_shard)"""
+        if mode not in ("base", "bucket"):
+            raise ValueError("mode is 'base' or 'bucket'")
         self.prover, self.pk, self.matrices = prover, pk, matrices
-        self.rank, self.world = rank, world_size
+        self.rank, self.world, self.mode = rank, world_size, mode
+        self.shard = (rank, world_size, "bucket") if mode == "bucket" and world_size > 1 else (rank, world_size)
 
     def local_partial(self, full_assignment: np.ndarray, r: np.ndarray) -> bytes:
-        return self.prover.prove_partial(self.pk, self.matrices, full_assignment, (self.rank, self.world),
-                                         skip_b_g1=not np.asarray(r).any())
+        return self.prover.prove_partial(self.pk, self.matrices, full_assignment, self.shard, skip_b_g1=not np.asarray(r).any())
 
     @staticmethod
     def exchange(local: bytes, dist, device=None) -> List[bytes]:
@@ -794,4 +869,4 @@ class ShardedProver:
     def prove(self, full_assignment: np.ndarray, r: np.ndarray, s: np.ndarray, dist=None, device=None) -> Proof:
         local = self.local_partial(full_assignment, r)
         parts = [local] if (dist is None or self.world == 1) else self.exchange(local, dist, device)
-        return self.prover.prove_finalize(self.pk, self.matrices.num_instance_variables, parts, r, s, (self.rank, self.world))
+        return self.prover.prove_finalize(self.pk, self.matrices.num_instance_variables, parts, r, s, self.shard)

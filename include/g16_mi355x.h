@@ -156,6 +156,41 @@ void* g16_ctx_stream(g16_ctx* ctx);
 int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out);
 void g16_pk_free(g16_pk* pk);
 
+/* BUCKET-SPACE SHARD of the five MSMs (src/prover.rs:66,74,262) over `world` ranks, the second way to cut them (the first: base
+ * ranges, g16_query.start / count above).  Every rank loads the WHOLE key (`view` as for one GPU: every query.start == 0) as
+ * window tables -- 31 GB at 2^22 BLS12-381 constraints, 126 GB at 2^24: what 288 GB of HBM per GPU are for -- and owns the buckets
+ * b with  b mod world == rank  of the merged-window bucket set (interleaved, so that the short top window's entries spread
+ * evenly).  A rank's sort keeps only the (point, window) entries of its residue class, its bucket passes fold ~1/world of them
+ * at the full window size (c = 20, W = 13, ~100 entries per bucket), and -- the point of the mode -- its bucket REDUCTIONS shrink
+ * world-fold too, which a base-range shard's do not (every rank keeps all 2^(c-1) buckets of all five MSMs there).  With local
+ * index k = b / world:  sum_{b owned} (b+1) S_b = world * sum_k (k+1) S_k + (rank + 1 - world) * sum_k S_k.
+ * g16_prove_partial / g16_prove_partial_h over such a key yield the rank's partial sums; the exchange (one all-gather of the
+ * g16_partial records) and g16_prove_finalize are unchanged.  The scalars are needed WHOLE on every rank: the assignment as for
+ * one GPU, and h either from the replicated witness map (g16_prove_partial) or -- distributed map -- all-gathered (n Fr; the
+ * ranks' blocks back to back, h_query loaded in that same order) and passed to g16_prove_partial_h.
+ * No silent fall-back: G16_ERR_OOM if the whole key's tables do not fit, G16_ERR_BAD_ARG for a key that cannot have tables
+ * (G16_MSM_PRECOMP=0) or a view that is itself a base-range shard.  world == 1 is g16_pk_load. */
+int g16_pk_load_bucket_shard(g16_ctx* ctx, const g16_pk_view* view, int rank, int world, g16_pk** out);
+/* The resident tables do not depend on the rank: re-label a whole key held as window tables (g16_pk_load, or a bucket-space shard)
+ * as rank `rank` of `world` (world == 1: the whole bucket set again).  Not while a call is using the key.  Lets one GPU walk through
+ * every rank's share (parity tests at 2^24, bench.py --sim-shards); a base-range shard or a plain-bases key is G16_ERR_BAD_ARG. */
+int g16_pk_rebind_bucket_shard(g16_pk* pk, int rank, int world);
+
+/* How a loaded key is held (no reference counterpart).  table_fallback says WHY a key is held as plain bases -- a slower prover:
+ * per-window buckets, c <= 16, more windows -- instead of window tables: 0 window tables (the default);
+ * 1 plain bases by request (G16_MSM_PRECOMP=0); 2 a query too long for merged entries; 3 the tables did not fit next to what
+ * already lives on the GPU (allocation failed, or G16_PK_TABLE_BUDGET_MB). */
+typedef struct {
+    int window_bits_z;      /* window size c of the witness MSMs' tables (0: plain bases)  */
+    int window_bits_h;      /* ... of h_query's                                          */
+    int table_fallback;     /* reason code above                                         */
+    int bucket_shard_rank;  /* g16_pk_load_bucket_shard: rank, world (0, 1 otherwise)    */
+    int bucket_shard_world;
+    int n_devices;          /* 1, or the devices of a multi-device key (fields above: device 0's shard) */
+    uint64_t device_bytes;  /* HBM held by the five query arrays (per device)            */
+} g16_pk_info;
+int g16_pk_get_info(const g16_pk* pk, g16_pk_info* out);
+
 /* num_variables = num_instance_variables + num_witness_variables (len of full_assignment) */
 int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_inputs, uint64_t num_constraints,
                      uint64_t num_variables, g16_circuit** out);
@@ -243,6 +278,10 @@ int g16_witness_map(g16_ctx* ctx, const g16_circuit* circuit, const uint64_t* fu
  * out: affine result */
 int g16_msm_g1(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine);
 int g16_msm_g2(g16_ctx* ctx, const uint64_t* bases, const uint64_t* scalars, uint64_t n, uint64_t* out_affine);
+/* rank's bucket-space share of the same MSM (g16_pk_load_bucket_shard's cut, window tables built on the fly): the `world`
+ * results add up to g16_msm_g1 / _g2 of the same inputs.  Parity tests. */
+int g16_msm_bucket_shard(g16_ctx* ctx, int g2, const uint64_t* bases, const uint64_t* scalars, uint64_t n, int rank, int world,
+                         uint64_t* out_affine);
 /* in place, natural order in and out, n = 2^log_n Fr in host memory */
 int g16_ntt(g16_ctx* ctx, uint64_t* data, int log_n, int inverse, int coset);
 
@@ -311,6 +350,9 @@ int g16_host_group_op(int curve, int g2, int op, const uint64_t* p, const uint64
  * checks digit extraction + bucket reduction + window fold logic without a GPU */
 int g16_host_msm_model(int curve, int g2, const uint64_t* bases, const uint64_t* scalars, uint64_t n, int c,
                        uint64_t* out_affine);
+/* the same model of rank's bucket-space share (c < 0: merged plan with window size -c) */
+int g16_host_msm_model_shard(int curve, int g2, const uint64_t* bases, const uint64_t* scalars, uint64_t n, int c, int rank,
+                             int world, uint64_t* out_affine);
 
 /* randomized CPU self-test of the reduced-radix (30-bit limb) arithmetic used by the bucket kernel against the
  * standard field / group code; 0 = all checks passed, otherwise the number of the first failing check */

@@ -132,6 +132,37 @@ def test_host_msm_model_buckets_per_lane(lb, orc, cp, c_win, G, monkeypatch):
 
 
 @pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("world", [2, 3, 5, 8, 64])
+@pytest.mark.parametrize("c_win", [-9, -12, -17, -20])
+def test_host_msm_model_bucket_shards_add_up(lb, orc, cp, c_win, world):
+    """bucket-space shards (g16_pk_load_bucket_shard): rank r keeps the entries whose bucket b has b mod world == r, re-indexes them
+    by k = b / world, reduces its LOCAL buckets and turns  sum_k (k+1) S_k, sum_k S_k  into its share
+    world * sum_k (k+1) S_k + (r + 1 - world) * sum_k S_k.  The CPU model of exactly that code (plan, filter, fold) for every rank;
+    the shares must add up to the oracle's MSM -- one class (c = 9), several (17, 20), rank counts that do not divide 2^(c-1)."""
+    cid = CURVE_ID[cp.name]
+    n = 60 if c_win <= -17 else 200
+    for g2 in (0, 1):
+        if g2 and (c_win != -12 or world not in (2, 5)):
+            continue
+        bases = orc.synth_bases(cp.name, bool(g2), 5, n)
+        sc = orc.rand_fr(cp.name, 177 + world - c_win, n)
+        p = cp.r
+        specials = ints_to_mont([0, 1, p - 1, 2, (p - 1) // 2, (p + 1) // 2], p, 4)
+        sc[: len(specials)] = specials
+        sc[20:50] = sc[20]   # one bucket per window holds 30 entries: all on one rank
+        bases[9] = 0
+        total = None
+        out = np.zeros(bases.shape[1], dtype=np.uint64)
+        for r in range(world):
+            assert lb.c.g16_host_msm_model_shard(cid, g2, ptr64(bases), ptr64(sc), n, c_win, r, world, ptr64(out)) == 0
+            total = out.copy() if total is None else orc.group_op(cp.name, bool(g2), 0, total, out)
+        assert (total == orc.msm(cp.name, bool(g2), bases, sc)).all(), (g2, c_win, world)
+    # per-window plans have no bucket-space shard; rank out of range
+    assert lb.c.g16_host_msm_model_shard(cid, 0, ptr64(bases), ptr64(sc), n, 5, 0, 2, ptr64(out)) != 0
+    assert lb.c.g16_host_msm_model_shard(cid, 0, ptr64(bases), ptr64(sc), n, -9, 2, 2, ptr64(out)) != 0
+
+
+@pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
 def test_host_selftest_fp30(lb, cp):
     """reduced-radix lazy arithmetic of the G1 bucket kernel (fp30.hpp) vs the standard field / group code"""
     for seed in (1, 2, 3):

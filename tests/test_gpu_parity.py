@@ -472,6 +472,11 @@ def test_bench_two_ranks_one_gpu(launcher):
     env.update(G16_BENCH_BACKEND="gloo", G16_BENCH_FORCE_DEVICE0="1", G16_BENCH_PRINT_PROOF="1")
     port = 29000 + os.getpid() % 2000
     tail = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2", "12", "--no-cpu-baseline", "--configs4", "on", "--configs4-log2", "13"]
+    # the two ways of cutting the MSMs over the ranks: "self" leaves the default (auto -> bucket-space shards: the whole key's tables
+    # fit easily at this size), "torchrun" forces base-range shards
+    want_mode = "bucket" if launcher == "self" else "base"
+    if launcher != "self":
+        tail += ["--shard-mode", "base"]
     if launcher == "self":
         cmd2 = [sys.executable, os.path.join(root, "bench.py")] + tail
     else:
@@ -488,6 +493,15 @@ def test_bench_two_ranks_one_gpu(launcher):
     d1 = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and d2["scaling"] == "strong"
     assert d2["proof_sha256"] == d1["proof_sha256"]
+    assert d2["config"]["shard_mode"] == want_mode and d2["config"]["pk"]["table_fallback"] == 0
+    assert d2["config"]["pk"]["bucket_shard_world"] == (2 if want_mode == "bucket" else 1)
+    assert d2["configs4"]["shard_mode"] == want_mode
+    # the single-GPU line carries the projected per-rank shares at 2 / 4 / 8 ranks under both cuts (measured on this GPU), and the
+    # key is whole again afterwards
+    ps = d1["projected_scaling"]
+    assert "error" not in ps and ps["headline_proof_unchanged_after"], ps
+    assert sorted((q["shard_mode"], q["n_gpus"]) for q in ps["points"]) == sorted((m, n) for m in ("base", "bucket") for n in (2, 4, 8))
+    assert all("error" not in q and q["rank_share_ms"] > 0 for q in ps["points"]), ps["points"]
     # the line proves its ranks: world size from the process group, one record per rank gathered through the collective
     assert d2["rccl_world"] == 2 and [r["rank"] for r in d2["ranks"]] == [0, 1] and len({r["pid"] for r in d2["ranks"]}) == 2
     assert "rccl_world" not in d1

@@ -1,4 +1,5 @@
-"""N > 1 path on CPU: two processes (gloo), each owning one contiguous shard of every MSM base array, exchange the
+"""N > 1 path on CPU: two processes (gloo), each owning one contiguous shard of every MSM base array (mode "base") or one residue
+class of the BUCKETS over all bases (mode "bucket", g16_pk_load_bucket_shard's cut), exchange the
 fixed-size partial records with ONE all-gather (the same ShardedProver.exchange that carries RCCL traffic on the GPUs)
 and each finishes the proof with g16_finalize_host.  The per-shard MSM sums come from the product's CPU model of the
 bucket method (g16_host_msm_model) because there is no GPU here; shard ranges, record layout, collective, N-way EC fold
@@ -35,7 +36,7 @@ def _xyzz_from_affine(aff: np.ndarray, one: np.ndarray, g2: bool) -> np.ndarray:
     return out
 
 
-def _worker(rank, world, port, curve, q):
+def _worker(rank, world, port, curve, q, mode="base"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
     sys.path.insert(0, os.path.dirname(HERE))
@@ -66,12 +67,20 @@ def _worker(rank, world, port, curve, q):
             n = min(len(bases), len(scalars))
             if n:
                 b, sc = np.ascontiguousarray(bases[:n]), np.ascontiguousarray(scalars[:n])
-                # rank 0 models the per-window bucket scheme, rank 1 the merged-window scheme of a key held as window tables:
-                # partial sums are group elements, so ranks need not agree on how they computed them
-                c_win = 0 if rank == 0 else -10
-                assert lb.c.g16_host_msm_model(CURVE_ID[curve], int(g2), ptr64(b), ptr64(sc), n, c_win, ptr64(out)) == 0
+                if mode == "bucket":
+                    # bucket-space shard: every rank sees ALL bases and scalars and owns the buckets b mod world == rank (the
+                    # product's own plan / filter / fold code, g16_host_msm_model_shard).  Unlike base-range shards, the ranks MUST agree
+                    # on the window size: the residue classes partition the buckets of ONE digit decomposition
+                    assert lb.c.g16_host_msm_model_shard(CURVE_ID[curve], int(g2), ptr64(b), ptr64(sc), n, -11, rank, world, ptr64(out)) == 0
+                else:
+                    # rank 0 models the per-window bucket scheme, rank 1 the merged-window scheme of a key held as window tables:
+                    # partial sums are group elements, so ranks need not agree on how they computed them
+                    c_win = 0 if rank == 0 else -10
+                    assert lb.c.g16_host_msm_model(CURVE_ID[curve], int(g2), ptr64(b), ptr64(sc), n, c_win, ptr64(out)) == 0
             return _xyzz_from_affine(out, one_fq, g2)
 
+        if mode == "bucket":
+            rg = g.shard_ranges(m, w, len(pk.h_query), nin, 0, 1)   # the bases are not cut
         (a_lo, a_hi), (l_lo, l_hi), (h_lo, h_hi) = rg["a"], rg["l"], rg["h"]
         part = PartialC()
         for name, val in (("h", msm(pk.h_query[h_lo:h_hi], h[h_lo:h_hi], False)),
@@ -100,13 +109,14 @@ def _worker(rank, world, port, curve, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["base", "bucket"])
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
-def test_two_rank_sharded_proof_gloo(curve):
+def test_two_rank_sharded_proof_gloo(curve, mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, curve, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, curve, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -115,10 +125,12 @@ def test_two_rank_sharded_proof_gloo(curve):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), res
-    # the shards tile every base array exactly once
     rg = {r[0]: r[2] for r in res}
     for key in ("a", "l", "h"):
-        assert rg[0][key][0] == 0 and rg[0][key][1] == rg[1][key][0]
+        if mode == "bucket":   # every rank holds every base
+            assert rg[0][key] == rg[1][key] and rg[0][key][0] == 0
+        else:                  # the shards tile every base array exactly once
+            assert rg[0][key][0] == 0 and rg[0][key][1] == rg[1][key][0]
 
 
 def test_shard_ranges_tile():
