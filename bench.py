@@ -409,9 +409,8 @@ def sim_share(p, n_ranks, mode, steps, warmup, use_dwm, ranks=(0,)):
                     part = p.partial()
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / steps
-                p.finalize([part] * n_ranks)
                 t1 = time.perf_counter()
-                p.finalize([part] * n_ranks)
+                p.finalize([part] * n_ranks)   # (picks up the (r, s)-only half the last partial() started: the real flow)
                 fin = time.perf_counter() - t1
                 got = dict(rank=r, partial_ms=1e3 * dt, finalize_ms=1e3 * fin, phases=p.timings(), pk_load_s=round(load_s, 3),
                            enqueue_ms=p.dwm_ms if dwm is not None else None)
@@ -559,8 +558,11 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("G16_BENCH_CPU_THREADS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-context throughput leg (reported as `pipelined`)")
-    ap.add_argument("--key", choices=["valid", "synthetic"], default=os.environ.get("G16_BENCH_KEY", "valid"),
-                    help="valid: CRS of the circuit generated on the GPU (g16_generate_parameters); synthetic: arbitrary distinct points")
+    ap.add_argument("--key", choices=["valid", "synthetic", "auto"], default=os.environ.get("G16_BENCH_KEY", "auto"),
+                    help="valid: CRS of the circuit generated on the GPU (g16_generate_parameters); synthetic: arbitrary distinct points "
+                         "(the same prover work); auto (default): valid on one GPU, synthetic with N > 1 ranks -- a valid CRS costs every "
+                         "rank ~10 s of HOST scalar work (Lagrange coefficients, the per-variable exponents), N ranks share one CPU quota, "
+                         "and that untimed setup must not be what a driver's clock around an 8-rank run sees")
     ap.add_argument("--configs4", choices=["auto", "on", "off"], default=os.environ.get("G16_BENCH_CONFIGS4", "auto"),
                     help="after the headline line's timed region, also time BASELINE.json configs[4] (2^24 constraints, BLS12-381, MSM bases "
                          "sharded over the ranks) and report it as the `configs4` field of the same JSON line; auto = when --gpus is 8 "
@@ -578,6 +580,9 @@ def main():
     args = ap.parse_args()
     if args.cpu_log2 <= 0:
         args.cpu_log2 = args.log2
+    key_was_auto = args.key == "auto"
+    if key_was_auto:
+        args.key = "valid" if (args.gpus == 1 and not args.sim_shards) or os.environ.get("G16_BENCH_PRINT_PROOF") else "synthetic"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU, exactly as the
@@ -662,9 +667,8 @@ def main():
             part = p.partial()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        p.finalize([part] * args.sim_shards)
         t1 = time.perf_counter()
-        p.finalize([part] * args.sim_shards)
+        p.finalize([part] * args.sim_shards)   # (picks up the (r, s)-only half the last partial() started: the real flow)
         fin = time.perf_counter() - t1
         print(json.dumps({"diagnostic": "per-rank share of a sharded proof (NOT a throughput number)", "sim_shards": args.sim_shards,
                           "shard_mode": p.mode, "log2": args.log2, "partial_ms": 1e3 * dt, "finalize_ms": 1e3 * fin, "phases": p.timings(),
@@ -807,6 +811,8 @@ def main():
                                    + ("valid proving key generated on the GPU from seeded toxic waste" if args.key == "valid"
                                       else "synthetic-bases proving key"),
                        "curve": args.curve, "log2_domain": args.log2, "constraints": p.nc, "key": args.key,
+                       "key_choice": ("auto: valid CRS on one GPU, synthetic bases with N > 1 ranks (bounds the untimed per-rank setup; any "
+                                      "distinct points give the same prover work)") if key_was_auto else "--key",
                        "untimed_setup_s": round(t_setup, 2), "pk_load_s": round(p.pk_load_s, 3),
                        "witness": "resident in HBM at entry (see value_incl_h2d for the PCIe-inclusive rates)",
                        "parallelism": ((f"msm-bucket-shard x{world} (whole window tables per GPU, buckets b mod {world} == rank)" if p.mode == "bucket"

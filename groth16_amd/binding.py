@@ -95,7 +95,8 @@ class PkInfoC(C.Structure):
 class TimingsC(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_a_ms", "msm_b_g1_ms", "msm_b_g2_ms", "scalar_prep_ms", "finish_ms",
-        "total_ms", "bucket_pass_ms")] + [("bucket_ms", C.c_double * 5), ("window_bits", C.c_double), ("windows", C.c_double), ("ntt_ms", C.c_double)]
+        "total_ms", "bucket_pass_ms")] + [("bucket_ms", C.c_double * 5), ("window_bits", C.c_double), ("windows", C.c_double), ("ntt_ms", C.c_double),
+                                  ("g1_pass_launches", C.c_double)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "bucket_ms"}
@@ -104,7 +105,7 @@ class TimingsC(C.Structure):
 
 
 EXPORTS = [
-    "g16_ctx_create", "g16_ctx_create_multi", "g16_ctx_num_devices", "g16_ctx_destroy", "g16_ctx_stream", "g16_pk_load", "g16_pk_free", "g16_circuit_load", "g16_circuit_free",
+    "g16_ctx_create", "g16_ctx_create_multi", "g16_ctx_num_devices", "g16_ctx_peer_access", "g16_ctx_destroy", "g16_ctx_stream", "g16_pk_load", "g16_pk_free", "g16_circuit_load", "g16_circuit_free",
     "g16_circuit_domain_size", "g16_prove", "g16_prove_partial", "g16_prove_finalize", "g16_finalize_host", "g16_prove_partial_h", "g16_dwm_create",
     "g16_dwm_free", "g16_dwm_local_size", "g16_dwm_stage", "g16_dwm_stage_async", "g16_ctx_wm_stream", "g16_prove_partial_prepare", "g16_prove_finalize_prepare", "g16_get_timings", "g16_diag_valu", "g16_witness_map",
     "g16_msm_g1", "g16_msm_g2", "g16_ntt", "g16_synth_bases", "g16_synth_circuit", "g16_host_field_op", "g16_host_group_op",
@@ -158,6 +159,7 @@ class Lib:
         c.g16_ctx_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         c.g16_ctx_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
         c.g16_ctx_num_devices.argtypes = [C.c_void_p]
+        c.g16_ctx_peer_access.argtypes = [C.c_void_p, C.c_int, C.c_int]
         c.g16_ctx_destroy.argtypes = [C.c_void_p]
         c.g16_ctx_destroy.restype = None
         c.g16_pk_load.argtypes = [C.c_void_p, C.POINTER(PkViewC), C.POINTER(C.c_void_p)]

@@ -89,6 +89,7 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
               hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipStreamCreateWithPriority(&c->stream_wm, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&c->stream_h2d, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_dwm, hipEventDisableTiming) == hipSuccess &&
               hipEventCreate(&c->ev_edge[0]) == hipSuccess && hipEventCreate(&c->ev_edge[1]) == hipSuccess &&
               hipEventCreate(&c->ev_edge[2]) == hipSuccess && hipEventCreate(&c->ev_edge[3]) == hipSuccess &&
@@ -108,6 +109,8 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
               hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 5; ++i)
         ok = hipEventCreate(&c->ev_done[i]) == hipSuccess;
+    for (int i = 0; ok && i < 8; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         g16::set_last_error("stream/event creation", hipGetLastError(), __FILE__, __LINE__);
         delete c;
@@ -142,16 +145,53 @@ int g16_ctx_create_multi(int curve, const int* device_ids, int n_dev, g16_ctx** 
         }
         c->subs.push_back(sub);
     }
-    // direct xGMI copies between the devices (the exchange of the distributed witness map); a refusal only means that
-    // hipMemcpyPeerAsync stages through the host
+    // Direct xGMI copies between the devices (the exchange of the distributed witness map).  Probed, not assumed: for every ordered
+    // pair of DISTINCT devices hipDeviceCanAccessPeer is asked first and the answer kept (g16_ctx_peer_access).  A pair without peer
+    // access still works -- hipMemcpyPeerAsync then stages through host memory -- but slowly, and a caller that sized its node for
+    // xGMI wants to know: G16_MULTI_REQUIRE_PEER=1 turns a refusal into G16_ERR_NO_PEER_ACCESS at create time instead of a slow prover.
+    // A pair that CAN be enabled and then fails to (anything but "already enabled") is an error in its own right.
+    // G16_MULTI_FAKE_NO_PEER=1 (tests: one physical GPU listed several times has no distinct pair) treats every pair as refused.
+    const bool require_peer = getenv("G16_MULTI_REQUIRE_PEER") && atoi(getenv("G16_MULTI_REQUIRE_PEER")) != 0;
+    const bool fake_refusal = getenv("G16_MULTI_FAKE_NO_PEER") && atoi(getenv("G16_MULTI_FAKE_NO_PEER")) != 0;
+    c->peer.assign((size_t)n_dev * (size_t)n_dev, 1);
+    auto fail = [&](int rc) {
+        for (g16_ctx* sub : c->subs) g16_ctx_destroy(sub);
+        delete c;
+        return rc;
+    };
     for (int a = 0; a < n_dev; ++a)
-        for (int b = 0; b < n_dev; ++b)
-            if (device_ids[a] != device_ids[b] && hipSetDevice(device_ids[a]) == hipSuccess) {
-                (void)hipDeviceEnablePeerAccess(device_ids[b], 0);
+        for (int b = 0; b < n_dev; ++b) {
+            if (a == b) continue;
+            int can = device_ids[a] == device_ids[b] ? 1 : 0;   // the same physical device: plain device-to-device copies
+            if (!can && hipDeviceCanAccessPeer(&can, device_ids[a], device_ids[b]) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+            if (fake_refusal) can = 0;
+            if (can && device_ids[a] != device_ids[b]) {
+                if (hipSetDevice(device_ids[a]) != hipSuccess) return fail(G16_ERR_HIP);
+                const hipError_t e = hipDeviceEnablePeerAccess(device_ids[b], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    g16::set_last_error("hipDeviceEnablePeerAccess (the pair reports peer capability)", e, __FILE__, __LINE__);
+                    return fail(G16_ERR_HIP);
+                }
                 (void)hipGetLastError();
             }
+            c->peer[(size_t)a * n_dev + b] = (char)can;
+            if (!can && require_peer) {
+                char buf[160];
+                snprintf(buf, sizeof(buf), "devices %d and %d of the context have no peer access (G16_MULTI_REQUIRE_PEER=1)", device_ids[a], device_ids[b]);
+                g_last_error = buf;
+                return fail(G16_ERR_NO_PEER_ACCESS);
+            }
+        }
     *out = c;
     return G16_OK;
+}
+
+int g16_ctx_peer_access(const g16_ctx* ctx, int i, int j) {
+    if (!ctx) return -1;
+    const int n = ctx->subs.empty() ? 1 : (int)ctx->subs.size();
+    if (i < 0 || j < 0 || i >= n || j >= n) return -1;
+    if (i == j || ctx->subs.empty()) return 1;
+    return ctx->peer[(size_t)i * n + j] ? 1 : 0;
 }
 
 int g16_ctx_num_devices(const g16_ctx* ctx) { return ctx ? (ctx->subs.empty() ? 1 : (int)ctx->subs.size()) : 0; }
@@ -169,6 +209,7 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream3);
     (void)hipStreamSynchronize(ctx->stream_wm);
+    (void)hipStreamSynchronize(ctx->stream_h2d);
     for (int i = 0; i < 5; ++i) (void)hipStreamSynchronize(ctx->red[i]);
     ctx->arena.release();
     ctx->t_wm.destroy(); ctx->t_prep_h.destroy(); ctx->t_prep_z.destroy(); ctx->t_ntt[0].destroy(); ctx->t_ntt[1].destroy();
@@ -179,6 +220,8 @@ void g16_ctx_destroy(g16_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_z); (void)hipEventDestroy(ctx->ev_h); (void)hipEventDestroy(ctx->ev_wm); (void)hipEventDestroy(ctx->ev_dwm);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_heavy[i]);
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev_edge[i]);
+    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev_up[i]);
+    (void)hipStreamDestroy(ctx->stream_h2d);
     (void)hipStreamDestroy(ctx->stream_wm);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipStreamDestroy(ctx->stream);
@@ -773,6 +816,7 @@ const char* g16_strerror(int status) {
         case G16_ERR_INTERNAL: return "internal error";
         case G16_ERR_UNEXPECTED_IDENTITY: return "unexpected identity: gamma or delta is zero";
         case G16_ERR_INVALID_DATA: return "invalid data: the bytes do not encode a point of the group";
+        case G16_ERR_NO_PEER_ACCESS: return "two devices of a multi-device context have no peer access (G16_MULTI_REQUIRE_PEER)";
         default: return "unknown status";
     }
 }

@@ -94,6 +94,8 @@ struct g16_ctx {
     hipStream_t stream;   // witness map, the five bucket passes back to back, the batched G1 reduction
     hipStream_t stream2;  // witness digit/sort pass beside the witness map; the G2 reduction of a whole-key proof
     hipStream_t stream3;  // h's digit/sort pass, underneath the first bucket pass
+    hipStream_t stream_h2d = nullptr;  // a host assignment's upload, in pieces (ZUpload): the mat-vec's row blocks follow piece by piece
+    hipEvent_t ev_up[8] = {};
     hipStream_t stream_wm = nullptr;   // g16_dwm_stage_async: the distributed witness map's stages (and the caller's exchanges between them)
     hipEvent_t ev_dwm = nullptr;
     hipEvent_t ev_heavy[4] = {};   // G1 MSM k's heavy-bucket combine (side stream) done
@@ -141,6 +143,7 @@ struct g16_ctx {
     size_t pinned_bytes = 0;
     // g16_ctx_create_multi: a multi-device context owns one full context per device and no device state of its own
     std::vector<g16_ctx*> subs;
+    std::vector<char> peer;   // [i * n + j]: device i reaches device j's memory directly (hipDeviceCanAccessPeer + enabled); see g16_ctx_peer_access
 };
 
 // Error exits of the entry points that launch on several streams: kernels still in flight reference arena memory that the
@@ -156,6 +159,7 @@ struct DrainOnError {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamSynchronize(ctx->stream3);
         (void)hipStreamSynchronize(ctx->stream_wm);
+        (void)hipStreamSynchronize(ctx->stream_h2d);
         for (int i = 0; i < 5; ++i) (void)hipStreamSynchronize(ctx->red[i]);
     }
 };

@@ -128,12 +128,26 @@ struct DeviceCircuit {
     Fr* val[3] = {nullptr, nullptr, nullptr};
     uint64_t nnz[3] = {0, 0, 0};
     Domain<C>* dom = nullptr;
+    // need_col[k]: the largest column any of the rows [0, (k + 1) n / Z_CHUNKS) of A, B, C reads (the instance copies of
+    // r1cs_to_qap.rs:195-199 included) -- computed once at g16_circuit_load.  A host assignment is uploaded in Z_CHUNKS pieces and the
+    // sparse mat-vec of row block k starts as soon as the piece holding need_col[k] has landed (ZUpload below).
+    static constexpr int Z_CHUNKS = 8;
+    uint64_t need_col[Z_CHUNKS] = {};
+};
+// a host assignment on its way to the device: witness_map_device issues the copies itself (in DeviceCircuit::Z_CHUNKS pieces on
+// `copy_stream`, one event each) and interleaves them with the row blocks of the mat-vec that each piece unlocks
+struct ZUpload {
+    const void* host = nullptr;      // n_assign field elements
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t landed[8] = {};       // landed[k]: piece k is in HBM; the LAST used one (index pieces - 1) covers the whole assignment
+    int pieces = 0;                  // out: how many pieces were used
 };
 // d_z: full assignment on device; d_h: n Fr out (natural order).  Scratch comes from the arena.
 // after the CSR upload: flag the unit coefficients in the DEVICE column indices (bit 31), see witness_map.hip
 template <class C> int mark_unit_coefficients(DeviceCircuit<C>* ck, hipStream_t st);
+// up != nullptr: d_z is an empty device buffer and the assignment still lies in host memory (ZUpload)
 template <class C> int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, typename C::Fr* d_h, Arena& arena,
-                                          hipStream_t st, EventTimer* ntt_timers = nullptr);
+                                          hipStream_t st, EventTimer* ntt_timers = nullptr, ZUpload* up = nullptr);
 
 // ---- distributed witness map (witness_map.hip): the same h over N ranks, one all-to-all per transform --------------------
 // n = N * M, blk = M / N (needs N^2 | n, N a power of two <= 16).  Two distributions of an n-vector over the ranks:
@@ -240,6 +254,16 @@ struct MsmBuffers {
 };
 template <class F> int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena,
                                        hipStream_t st, MsmBuffers<F>* out, EventTimer* bucket_timer);
+// the bucket passes of n <= 4 MSMs over one bucket layout (B, groups, segment length) as ONE launch: one tail instead of n
+template <class F>
+struct PassJob {
+    const Affine<F>* bases;
+    int64_t shift;
+    uint64_t base_count;
+    const ScalarSort* ss;
+    MsmBuffers<F>* out;
+};
+template <class F> int msm_bucket_pass_batch(const PassJob<F>* jobs, int n, Arena& arena, hipStream_t st, EventTimer* bucket_timer);
 template <class F> int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st);
 // the reductions of n <= 4 MSMs whose plans have the same bucket layout as ONE launch per stage (they fill the chip together
 // instead of each occupying a corner of it underneath the next MSM's bucket pass); G16_ERR_INTERNAL if the plans differ

@@ -265,6 +265,20 @@ struct KeyLoader {
                     return fail(G16_ERR_HIP);
             }
         }
+        {   // need_col (DeviceCircuit): prefix maximum of the columns read by the rows of each of the Z_CHUNKS row blocks of the domain
+            constexpr int ZC = DeviceCircuit<C>::Z_CHUNKS;
+            const uint64_t n_dom = (uint64_t)1 << log_n;
+            uint64_t run = 0;
+            for (int k = 0; k < ZC; ++k) {
+                const uint64_t r_lo = n_dom * (uint64_t)k / ZC, r_hi = n_dom * (uint64_t)(k + 1) / ZC;
+                for (int m = 0; m < 3; ++m) {
+                    const uint64_t a = std::min(r_lo, num_constraints), b = std::min(r_hi, num_constraints);
+                    for (uint64_t e = abc[m].row_ptr[a]; e < abc[m].row_ptr[b]; ++e) run = std::max<uint64_t>(run, abc[m].col[e]);
+                }
+                if (r_hi > num_constraints && num_inputs) run = std::max(run, std::min(r_hi - num_constraints, num_inputs) - 1);   // a[nc + j] = z[j]
+                dc->need_col[k] = run;
+            }
+        }
         int rc = mark_unit_coefficients<C>(dc, ctx->stream);
         if (rc) return fail(rc);
         rc = domain_create<C>(log_n, ctx->stream, &dc->dom);

@@ -258,7 +258,11 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_merged_ker
 static constexpr int SCAN_THREADS = 256;
 static constexpr int SCAN_PER_THREAD = 8;
 static constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
-static constexpr uint32_t HEAVY_PARTS = 8;   // a bucket with more partial sums than this is combined cooperatively
+// A bucket with more partial sums than this is combined cooperatively by a workgroup (heavy_reduce_kernel: FEW buckets with MANY partial
+// sums -- the top window's short digit range, repeated scalars); up to this many are added up by one lane (bucket_combine_kernel).
+// 8 until round 5: a bucket-space shard's top-window buckets hold ~2x the mean (224 entries = 8 - 9 segments of 32), thousands of them
+// just over the threshold, and the cooperative kernel -- a 128-lane tree per bucket -- took 0.5 - 0.9 ms per MSM in the tail of the proof.
+static constexpr uint32_t HEAVY_PARTS = 16;
 
 // exclusive scan of one value per thread across the workgroup; returns the workgroup total through *total
 __device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* sh, uint32_t* total) {
@@ -463,11 +467,34 @@ __device__ __forceinline__ Acc30<F30> gather_acc(const St& st, bool inf) {
     return a;
 }
 
+// ONE launch walks up to PASS_BATCH MSMs (blockIdx.y = MSM of the batch: its own bases, sorted list, offsets and partial-sum slots; one
+// plan).  A pass ends with a tail -- the last segments run on a chip that is emptying: about half a segment's time when the lanes are
+// re-filled dynamically -- and a launch's tail cannot be filled by the next launch of the same stream.  The G1 MSMs of a proof that are
+// ready together (l, a, b_g1 share the witness sort; h joins when its sort is done in time) therefore go as ONE launch: one tail
+// instead of three or four (a rank's share of an 8-way sharded 2^22 proof: 1.3-1.4 ms per pass of 1.1 ms of work, round 5).
+static constexpr int PASS_BATCH = 4;
+template <class F30>
+struct PassBatch {
+    const Affine<typename F30::Std>* bases[PASS_BATCH];
+    int64_t shift[PASS_BATCH];
+    uint64_t base_count[PASS_BATCH];
+    const uint32_t* sorted[PASS_BATCH];
+    const uint32_t* offsets[PASS_BATCH];
+    const uint32_t* slot_off[PASS_BATCH];
+    AccRaw<typename F30::Raw>* partials[PASS_BATCH];
+};
+
 template <class F30, bool DIRECT>
 __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumulate30_kernel(
-    const Affine<typename F30::Std>* __restrict__ bases, int64_t shift, uint64_t base_count, const uint32_t* __restrict__ sorted,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ slot_off, uint32_t M, uint32_t off_shift, uint32_t lseg,
-    uint32_t merged, AccRaw<typename F30::Raw>* __restrict__ partials) {
+    PassBatch<F30> batch, uint32_t M, uint32_t off_shift, uint32_t lseg, uint32_t merged) {
+    // (uniform index: the seven values come out of the kernel arguments with scalar loads)
+    const Affine<typename F30::Std>* __restrict__ bases = batch.bases[blockIdx.y];
+    const int64_t shift = batch.shift[blockIdx.y];
+    const uint64_t base_count = batch.base_count[blockIdx.y];
+    const uint32_t* __restrict__ sorted = batch.sorted[blockIdx.y];
+    const uint32_t* __restrict__ offsets = batch.offsets[blockIdx.y];
+    const uint32_t* __restrict__ slot_off = batch.slot_off[blockIdx.y];
+    AccRaw<typename F30::Raw>* __restrict__ partials = batch.partials[blockIdx.y];
     const uint32_t t = (blockIdx.x * ACC_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
     const uint32_t S = offsets[M] >> off_shift;                                            // entries in total
     const uint64_t start64 = (uint64_t)t * lseg;
@@ -665,6 +692,38 @@ __global__ __launch_bounds__(HEAVY_THREADS, REDUCE_STREAMED<F30> ? 2 : 1) void h
 }
 
 // ---------------------------------------------------------------------------------------------
+// 5c. every other bucket with more than one partial sum (2 .. HEAVY_PARTS of them): ONE task per BUCKET adds them up into the bucket's
+//     first slot, so that the bucket reduction below -- one lane per G buckets, a chain of dependent additions whose length IS the time
+//     it takes (a lone wave issues a dependent instruction every ~7.5 cycles: ~27 us per G1 addition) -- reads one sum per bucket:
+//     G (np + 1) additions per lane become (np - 1) here, spread over G times the lanes, and 2 G there.  Round 5: the reductions are
+//     what a rank's share of a sharded proof ends with (8-way at 2^22: 1.0 ms -> 0.45 ms of bucket level per G1 batch), and the G2
+//     reduction runs its chain underneath the G1 passes.
+// ---------------------------------------------------------------------------------------------
+template <class F30>
+__global__ __launch_bounds__(RED_THREADS, 2) void bucket_combine_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t M) {
+    AccRaw<typename F30::Raw>* __restrict__ partials = batch.partials[blockIdx.y];
+    const uint32_t* __restrict__ slot_off = batch.slot_off[blockIdx.y];
+    const uint32_t b = (blockIdx.x * RED_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
+    if (b >= M) return;
+    const uint32_t t0 = slot_off[b], np = slot_off[b + 1] - t0;
+    if (np < 2 || np > HEAVY_PARTS) return;   // (heavy buckets were combined into [t0] by heavy_reduce_kernel)
+    if constexpr (REDUCE_STREAMED<F30>) {
+        const RawAccStore<F30> mine{&partials[t0]};
+        bool inf = mine.inf();
+        const bool was = inf;
+        for (uint32_t q = 1; q < np; ++q) {
+            const RawAccStore<F30> src{&partials[t0 + q]};
+            acc_add_streamed<F30>(mine, inf, src, src.inf());
+        }
+        if (inf && !was) mine.set_inf();
+    } else {
+        Acc30<F30> acc = Acc30<F30>::load_raw(partials[t0]);
+        for (uint32_t q = 1; q < np; ++q) acc.add(Acc30<F30>::load_raw(partials[t0 + q]));
+        acc.store_raw(&partials[t0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 6. bucket reduction: chunk of G buckets per lane, then one workgroup per window
 // ---------------------------------------------------------------------------------------------
 template <class F30>
@@ -698,10 +757,8 @@ __global__ __launch_bounds__(RED_THREADS, (F30::LANES_PER_TASK == 1 || REDUCE_ST
         for (uint32_t bb = G; bb-- > 0;) {
             const uint32_t gb = w * B + b_lo + bb;
             const uint32_t t0 = slot_off[gb];
-            uint32_t np = slot_off[gb + 1] - t0;
-            if (np > HEAVY_PARTS) np = 1;  // pre-combined into [t0] by heavy_reduce_kernel
-            for (uint32_t q = 0; q < np; ++q) {
-                const RawAccStore<F30> src{const_cast<AccRaw<typename F30::Raw>*>(&partials[t0 + q])};
+            if (slot_off[gb + 1] != t0) {   // the bucket's partial sums were combined into [t0] (heavy_reduce_kernel / bucket_combine_kernel)
+                const RawAccStore<F30> src{const_cast<AccRaw<typename F30::Raw>*>(&partials[t0])};
                 acc_add_streamed<F30>(run_s, run_inf, src, src.inf());
             }
             acc_add_streamed<F30>(tot_s, tot_inf, run_s, run_inf);
@@ -713,9 +770,7 @@ __global__ __launch_bounds__(RED_THREADS, (F30::LANES_PER_TASK == 1 || REDUCE_ST
     for (uint32_t bb = G; bb-- > 0;) {
         const uint32_t gb = w * B + b_lo + bb;
         const uint32_t t0 = slot_off[gb];
-        uint32_t np = slot_off[gb + 1] - t0;
-        if (np > HEAVY_PARTS) np = 1;  // pre-combined into [t0] by heavy_reduce_kernel
-        for (uint32_t q = 0; q < np; ++q) run.add(Acc30<F30>::load_raw(partials[t0 + q]));
+        if (slot_off[gb + 1] != t0) run.add(Acc30<F30>::load_raw(partials[t0]));   // combined into [t0] by the two kernels above
         tot.add(run);
     }
     // sum_b (b+1) S_b over the chunk = tot + b_lo * run: the b_lo * run part is assembled from bit-plane sums of `run` over
@@ -1036,7 +1091,11 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
         return G16_OK;
     };
     // merged plan: ~2048 workgroups over the class regions (a class region may hold anything between nothing and all entries)
-    const unsigned gx = std::max(1u, std::min(2048u / Q, (unsigned)((nw + SORT_THREADS - 1) / SORT_THREADS)));
+    unsigned gx = std::max(1u, std::min(2048u / Q, (unsigned)((nw + SORT_THREADS - 1) / SORT_THREADS)));
+    if (const char* e = getenv("G16_SORT_GX")) {   // experiments: workgroups per class of the merged counting sort
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4096) gx = (unsigned)v;
+    }
     if (n) {
         if (plan.merged) {
             hipLaunchKernelGGL((class_count_kernel<Fr>), dim3(nb), dim3(CLASS_THREADS), 0, st, d_scalars, n, pd, blog, Q, class_cnt);
@@ -1071,6 +1130,21 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     return G16_OK;
 }
 
+// buffers of one MSM's pass and reductions
+template <class F>
+static int alloc_msm_buffers(const ScalarSort& ss, Arena& arena, MsmBuffers<F>* out) {
+    typedef AccRaw<typename Lazy30<F>::type::Raw> Raw;
+    const MsmPlan& plan = ss.plan;
+    const uint32_t cpw = plan.B / plan.chunk_buckets();
+    Raw *partials = nullptr, *chunk_out = nullptr;
+    G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
+    G16_TRY(arena.alloc_n((size_t)cpw * plan.groups * 2, &chunk_out));   // weighted chunk sums, then plain chunk sums
+    G16_TRY(arena.alloc_n((size_t)plan.outputs(), &out->window_sums));
+    out->partials = partials;
+    out->chunk_out = chunk_out;
+    return G16_OK;
+}
+
 template <class F>
 int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count, const ScalarSort& ss, Arena& arena, hipStream_t st,
                     MsmBuffers<F>* out, EventTimer* bucket_timer) {
@@ -1078,15 +1152,13 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
     typedef AccRaw<typename Lazy30<F>::type::Raw> Raw;
     const MsmPlan& plan = ss.plan;
     const uint32_t M = plan.buckets();
-    const uint32_t G = plan.chunk_buckets();
-    const uint32_t cpw = plan.B / G;
     const int R = plan.affine_levels;
-    Raw *partials = nullptr, *chunk_out = nullptr;
-    G16_TRY(arena.alloc_n((size_t)ss.max_tasks ? ss.max_tasks : 1, &partials));
-    G16_TRY(arena.alloc_n((size_t)cpw * plan.groups * 2, &chunk_out));   // weighted chunk sums, then plain chunk sums
-    G16_TRY(arena.alloc_n((size_t)plan.outputs(), &out->window_sums));
-    out->partials = partials;
-    out->chunk_out = chunk_out;
+    if (!R || !ss.max_sorted) {
+        const PassJob<F> job{d_bases, shift, base_count, &ss, out};
+        return msm_bucket_pass_batch<F>(&job, 1, arena, st, bucket_timer);
+    }
+    G16_TRY(alloc_msm_buffers<F>(ss, arena, out));
+    Raw* partials = static_cast<Raw*>(out->partials);
     // batched-affine levels: two ping-pong lists (level 1 holds max_sorted / 2 points, level 2 a quarter, level 3 reuses the
     // first, ...) and the prefix-product scratch of the widest level
     Affine<F>* lists[2] = {nullptr, nullptr};
@@ -1100,7 +1172,7 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
         return K;
     };
     auto level_waves = [&](int r) -> uint64_t { return ((ss.max_sorted >> (r + 1)) + (uint64_t)level_K(r) * T - 1) / ((uint64_t)level_K(r) * T); };
-    if (R && ss.max_sorted) {
+    {
         G16_TRY(arena.alloc_n((size_t)(ss.max_sorted >> 1) + 1, &lists[0]));
         if (R > 1) G16_TRY(arena.alloc_n((size_t)(ss.max_sorted >> 2) + 1, &lists[1]));
         size_t recs = 0;
@@ -1108,8 +1180,7 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
         G16_TRY(arena.alloc_n(recs ? recs : 1, &prefix));
     }
     if (bucket_timer) G16_TRY(bucket_timer->start(st));
-    const Affine<F>* walk = d_bases;
-    if (R && ss.max_sorted) {
+    {
         AffineLevelArgs<F30> a;
         a.sorted = ss.sorted;
         a.total = ss.offsets + M;
@@ -1128,17 +1199,49 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
             else hipLaunchKernelGGL((affine_level_kernel<F30, false>), dim3(blocks), dim3(AFF_THREADS), 0, st, a);
             G16_LAUNCH_CHECK();
         }
-        walk = lists[(R - 1) & 1];
     }
     if (ss.max_segments) {
         const uint64_t lanes = (uint64_t)ss.max_segments * F30::LANES_PER_TASK;
         const dim3 grid((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS));
-        if (R)
-            hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, true>), grid, dim3(ACC_THREADS), 0, st, walk, (int64_t)0, (uint64_t)0,
-                               (const uint32_t*)nullptr, ss.offsets, ss.task_off, M, (uint32_t)R, plan.Lmax, 0u, partials);
-        else
-            hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, false>), grid, dim3(ACC_THREADS), 0, st, d_bases, shift, base_count, ss.sorted,
-                               ss.offsets, ss.task_off, M, 0u, plan.Lmax, plan.merged ? 1u : 0u, partials);
+        PassBatch<F30> b;
+        for (int i = 0; i < PASS_BATCH; ++i) {
+            b.bases[i] = lists[(R - 1) & 1]; b.shift[i] = 0; b.base_count[i] = 0; b.sorted[i] = nullptr;
+            b.offsets[i] = ss.offsets; b.slot_off[i] = ss.task_off; b.partials[i] = partials;
+        }
+        hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, true>), grid, dim3(ACC_THREADS), 0, st, b, M, (uint32_t)R, plan.Lmax, 0u);
+        G16_LAUNCH_CHECK();
+    }
+    if (bucket_timer) G16_TRY(bucket_timer->stop(st));
+    return G16_OK;
+}
+
+// the bucket passes of n <= PASS_BATCH MSMs with one bucket layout as ONE launch (PassBatch above)
+template <class F>
+int msm_bucket_pass_batch(const PassJob<F>* jobs, int n, Arena& arena, hipStream_t st, EventTimer* bucket_timer) {
+    typedef typename Lazy30<F>::acc_type F30;
+    typedef AccRaw<typename Lazy30<F>::type::Raw> Raw;
+    if (n < 1 || n > PASS_BATCH) return G16_ERR_INTERNAL;
+    const MsmPlan& plan = jobs[0].ss->plan;
+    for (int i = 0; i < n; ++i) {
+        const MsmPlan& q = jobs[i].ss->plan;
+        if (q.B != plan.B || q.groups != plan.groups || q.Lmax != plan.Lmax || q.merged != plan.merged) return G16_ERR_INTERNAL;
+        if (q.affine_levels && jobs[i].ss->max_sorted) return G16_ERR_INTERNAL;   // that plan walks level lists: msm_bucket_pass
+    }
+    PassBatch<F30> b;
+    uint32_t max_segments = 0;
+    for (int i = 0; i < n; ++i) G16_TRY(alloc_msm_buffers<F>(*jobs[i].ss, arena, jobs[i].out));
+    for (int i = 0; i < PASS_BATCH; ++i) {
+        const PassJob<F>& j = jobs[i < n ? i : 0];
+        b.bases[i] = j.bases; b.shift[i] = j.shift; b.base_count[i] = j.base_count; b.sorted[i] = j.ss->sorted;
+        b.offsets[i] = j.ss->offsets; b.slot_off[i] = j.ss->task_off; b.partials[i] = static_cast<Raw*>(j.out->partials);
+        if (i < n) max_segments = std::max(max_segments, j.ss->max_segments);
+    }
+    if (bucket_timer) G16_TRY(bucket_timer->start(st));
+    if (max_segments) {
+        const uint64_t lanes = (uint64_t)max_segments * F30::LANES_PER_TASK;
+        const dim3 grid((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS), (unsigned)n);
+        hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, false>), grid, dim3(ACC_THREADS), 0, st, b, plan.buckets(), 0u, plan.Lmax,
+                           plan.merged ? 1u : 0u);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));
@@ -1187,7 +1290,11 @@ int msm_heavy_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t
     G16_TRY(reduce_setup<F>(&lds_heavy, &lds_win));
     const MsmBuffers<F>* b = &buf;
     const ScalarSort* s = &ss;
-    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, 1), dim3(HEAVY_THREADS), lds_heavy, st, make_reduce_batch<F>(&b, &s, 1));
+    const auto batch = make_reduce_batch<F>(&b, &s, 1);
+    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, 1), dim3(HEAVY_THREADS), lds_heavy, st, batch);
+    G16_LAUNCH_CHECK();
+    const uint32_t M = ss.plan.buckets();
+    hipLaunchKernelGGL((bucket_combine_kernel<F30>), dim3((M * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, 1), dim3(RED_THREADS), 0, st, batch, M);
     G16_LAUNCH_CHECK();
     return G16_OK;
 }
@@ -1206,6 +1313,9 @@ int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* 
     const auto batch = make_reduce_batch<F>(bufs, sorts, n);
     if (!heavy_done) {
         hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, n), dim3(HEAVY_THREADS), lds_heavy, st, batch);
+        G16_LAUNCH_CHECK();
+        const uint32_t M = plan.buckets();
+        hipLaunchKernelGGL((bucket_combine_kernel<F30>), dim3((M * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, n), dim3(RED_THREADS), 0, st, batch, M);
         G16_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, n), dim3(RED_THREADS), 0,
@@ -1337,6 +1447,8 @@ int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine
                                                  hipStream_t, MsmBuffers<typename C::Fq>*, EventTimer*);                      \
     template int msm_bucket_pass<typename C::Fq2>(const Affine<typename C::Fq2>*, int64_t, uint64_t, const ScalarSort&,     \
                                                   Arena&, hipStream_t, MsmBuffers<typename C::Fq2>*, EventTimer*);            \
+    template int msm_bucket_pass_batch<typename C::Fq>(const PassJob<typename C::Fq>*, int, Arena&, hipStream_t, EventTimer*);   \
+    template int msm_bucket_pass_batch<typename C::Fq2>(const PassJob<typename C::Fq2>*, int, Arena&, hipStream_t, EventTimer*); \
     template int msm_reduce<typename C::Fq>(const MsmBuffers<typename C::Fq>&, const ScalarSort&, hipStream_t);             \
     template int msm_reduce_batch<typename C::Fq>(const MsmBuffers<typename C::Fq>* const*, const ScalarSort* const*, int, hipStream_t, bool); \
     template int msm_heavy_reduce<typename C::Fq>(const MsmBuffers<typename C::Fq>&, const ScalarSort&, hipStream_t);     \

@@ -74,8 +74,21 @@ struct Prover {
         if (prepared) ctx->prep.valid = false;   // consumed: the arena keeps its contents for this call
         else ctx->reset_arena();
         const Fr* d_z = nullptr;
-        G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
-        if (!prepared) G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));
+        // a host assignment with the witness map running here: uploaded in pieces BY the map, whose mat-vec follows the pieces
+        // (witness_map_device / ZUpload); every other reader of z waits for the last piece.  G16_UPLOAD_CHUNKED=0: one copy (A/B).
+        ZUpload up;
+        const bool chunked = !on_device && !h_ext && !prepared && !(getenv("G16_UPLOAD_CHUNKED") && atoi(getenv("G16_UPLOAD_CHUNKED")) == 0);
+        if (chunked) {
+            Fr* buf = nullptr;
+            G16_TRY(ctx->arena.alloc_n(n_assign, &buf));
+            d_z = buf;
+            up.host = z;
+            up.copy_stream = ctx->stream_h2d;
+            for (int i = 0; i < 8; ++i) up.landed[i] = ctx->ev_up[i];
+        } else {
+            G16_TRY(stage_assignment(ctx, z, n_assign, on_device, &d_z));
+            if (!prepared) G16_HIP_TRY(hipEventRecord(ctx->ev_z, s1));
+        }
 
         // ---- witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it.  It goes FIRST,
         // alone, on stream 1 (~6 ms at 2^22): underneath the bucket passes their long-lived waves starve it (60+ ms
@@ -98,7 +111,8 @@ struct Prover {
         } else {
             G16_TRY(ctx->arena.alloc_n(n, &d_h));
             RoctxRange rr("R1CS to QAP witness map");                                                    // prover.rs:36
-            G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1, ctx->t_ntt)));
+            G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1, ctx->t_ntt, chunked ? &up : nullptr)));
+            if (chunked) G16_HIP_TRY(hipEventRecord(ctx->ev_z, ctx->stream_h2d));   // behind the last piece: the whole assignment is in HBM
         }
         G16_TRY(ctx->t_wm.stop(s1));
         G16_HIP_TRY(hipEventRecord(ctx->ev_wm, s1));
@@ -145,18 +159,24 @@ struct Prover {
         // before it starts the next kernel, and the four of them cost ~0.13 ms of idle GPU between two passes (kernel trace of round 3).
         hipEvent_t pass_begin[5] = {}, pass_end[5] = {}, last_end = nullptr;
         int n_edge = 0;
-        auto mark = [&](hipEvent_t* ev) -> int {
+        auto mark = [&](hipEvent_t* ev, hipStream_t on = nullptr) -> int {
             if (n_edge >= 8) return G16_ERR_INTERNAL;
             *ev = ctx->ev_edge[n_edge++];
-            G16_HIP_TRY(hipEventRecord(*ev, s1));
+            G16_HIP_TRY(hipEventRecord(*ev, on ? on : s1));
             return G16_OK;
         };
-        auto run_pass = [&](int k, auto* bases, int64_t shift, uint64_t count, const ScalarSort& ss, auto* buf) -> int {
-            if (last_end) pass_begin[k] = last_end;
-            else G16_TRY(mark(&pass_begin[k]));
-            G16_TRY((msm_bucket_pass(bases, shift, count, ss, ctx->arena, s1, buf, nullptr)));
-            G16_TRY(mark(&pass_end[k]));
-            last_end = pass_end[k];
+        // The G2 pass (and its reduction) on its own queue beside the G1 passes of stream 1, so that the dispatcher fills the tail of one
+        // kernel with workgroups of the other: on for the SHORT passes of a sharded proof, where a tail is 10-15 % of a pass (8-way share
+        // at 2^22, same box: 11.04 -> 10.91 ms bucket-space, 12.31 -> 12.23 base ranges); off for whole-key proofs, where it only delays
+        // the G2 reduction towards the end of the proof (67.8 / 68.2 vs 68.3 ms).  G16_PASS_CONCURRENT=0 / 1 forces.
+        bool concurrent = short_passes;
+        if (const char* e = getenv("G16_PASS_CONCURRENT")) concurrent = atoi(e) != 0;
+        auto run_pass = [&](int k, auto* bases, int64_t shift, uint64_t count, const ScalarSort& ss, auto* buf, hipStream_t on = nullptr) -> int {
+            if (last_end && !on) pass_begin[k] = last_end;
+            else G16_TRY(mark(&pass_begin[k], on));
+            G16_TRY((msm_bucket_pass(bases, shift, count, ss, ctx->arena, on ? on : s1, buf, nullptr)));
+            G16_TRY(mark(&pass_end[k], on));
+            if (!on) last_end = pass_end[k];
             return G16_OK;
         };
         // a G1 MSM's heavy-bucket combine (buckets with many partial sums: the short top window's few hundred) goes underneath the
@@ -179,43 +199,87 @@ struct Prover {
         {
             hipStream_t sr = short_passes ? ctx->red[4] : s2;
             RoctxRange rr("Compute B in G2");                                                                 // prover.rs:111
-            G16_TRY(run_pass(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2));                               // prover.rs:113
-            G16_HIP_TRY(hipStreamWaitEvent(sr, pass_end[4], 0));
+            if (concurrent) {
+                G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_z, 0));
+                G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_wm, 0));   // never underneath the witness map (it would starve)
+                G16_TRY(run_pass(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2, sr));
+            } else {
+                G16_TRY(run_pass(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2));                           // prover.rs:113
+                G16_HIP_TRY(hipStreamWaitEvent(sr, pass_end[4], 0));
+            }
             G16_TRY((msm_reduce(buf_b2, sort_z, sr)));
             G16_TRY(copy_out(4, buf_b2, sort_z, sr));
         }
         struct G1Job { int k; MsmBuffers<Fq>* buf; const ScalarSort* ss; };
         G1Job jobs[4];
         int njobs = 0;
+        // The G1 passes that are ready together go as ONE launch (msm_bucket_pass_batch: one tail instead of one per MSM): a and b_g1
+        // always (one sort, equal counts), l when it reuses the witness sort, and h when its sort is certain to be done by then -- the
+        // sharded proof, where the passes wait for the distributed map anyway and h's sort is a few hundred microseconds.  On one GPU
+        // h's sort runs starved underneath the passes (stream 3) and finishes late: there the h pass stays a launch of its own at the end.
+        PassJob<Fq> pj[4];
+        int pk_of[4], npj = 0;
+        double weight[5] = {0, 0, 0, 0, 0};   // a batch's time is shared out by the points of its members (one W: entries ~ points)
+        auto plans_match = [](const MsmPlan& x, const MsmPlan& y) {
+            return x.B == y.B && x.groups == y.groups && x.Lmax == y.Lmax && x.merged == y.merged && x.affine_levels == 0 && y.affine_levels == 0;
+        };
+        const bool batch_ok = sort_z.plan.affine_levels == 0 || sort_z.max_sorted == 0;
+        const bool h_in_batch = h_ext != nullptr && batch_ok && plans_match(sort_z.plan, sort_h.plan) && !getenv("G16_PASS_NO_BATCH");
+        int g1_launches = 0;
+        bool last_batch = false, early[4] = {false, false, false, false};
+        auto run_batch = [&]() -> int {   // whatever is queued in pj[]
+            if (!npj) return G16_OK;
+            hipEvent_t b0, b1;
+            if (last_end) b0 = last_end;
+            else G16_TRY(mark(&b0));
+            if (batch_ok && !getenv("G16_PASS_NO_BATCH")) {
+                G16_TRY((msm_bucket_pass_batch<Fq>(pj, npj, ctx->arena, s1, nullptr)));
+                ++g1_launches;
+            } else {
+                for (int i = 0; i < npj; ++i) {
+                    G16_TRY((msm_bucket_pass<Fq>(pj[i].bases, pj[i].shift, pj[i].base_count, *pj[i].ss, ctx->arena, s1, pj[i].out, nullptr)));
+                    ++g1_launches;
+                }
+            }
+            G16_TRY(mark(&b1));
+            last_end = b1;
+            for (int i = 0; i < npj; ++i) { pass_begin[pk_of[i]] = b0; pass_end[pk_of[i]] = b1; }
+            // the first stage of an MSM's reduction (heavy-bucket combine, then one sum per bucket) goes underneath the NEXT pass on the
+            // MSM's own stream; after the last pass there is nothing to hide under, and the batched reduction runs that stage itself
+            if (!last_batch)
+                for (int i = 0; i < npj; ++i) { G16_TRY(heavy_early(pk_of[i], *pj[i].out, *pj[i].ss)); early[pk_of[i]] = true; }
+            npj = 0;
+            return G16_OK;
+        };
+        auto queue_pass = [&](int k, const G1A* bases, int64_t shift, uint64_t count, const ScalarSort& ss, MsmBuffers<Fq>* buf) {
+            pj[npj] = PassJob<Fq>{bases, shift, count, &ss, buf};
+            pk_of[npj++] = k;
+            weight[k] = (double)count;
+            jobs[njobs++] = {k, buf, &ss};
+        };
         if (l_covered) {
             const int64_t shift = (int64_t)pk->a_start - (int64_t)(nin - 1) - (int64_t)pk->l_start;
-            G16_TRY(run_pass(1, pk->l, shift, pk->l_count, sort_z, &buf_l));
-            G16_TRY(heavy_early(1, buf_l, sort_z));
-            jobs[njobs++] = {1, &buf_l, &sort_z};
+            queue_pass(1, pk->l, shift, pk->l_count, sort_z, &buf_l);
         } else {
             G16_TRY((sort_scalars<C>(d_z + nin + pk->l_start, pk->l_count, pk->c_z, ctx->arena, s1, &sort_l, pk->shard_n, pk->shard_r)));
             last_end = nullptr;   // the sort sits between the passes: this one gets its own begin mark
-            G16_TRY(run_pass(1, pk->l, 0, pk->l_count, sort_l, &buf_l));
-            G16_TRY(heavy_early(1, buf_l, sort_l));
-            jobs[njobs++] = {1, &buf_l, &sort_l};
+            queue_pass(1, pk->l, 0, pk->l_count, sort_l, &buf_l);
+            G16_TRY(run_batch());
         }
         { RoctxRange rr("Compute A");                                                                        // prover.rs:89
-        G16_TRY(run_pass(2, pk->a, 0, pk->a_count, sort_z, &buf_a)); }                                       // prover.rs:92
-        G16_TRY(heavy_early(2, buf_a, sort_z));
-        jobs[njobs++] = {2, &buf_a, &sort_z};
+        queue_pass(2, pk->a, 0, pk->a_count, sort_z, &buf_a); }                                              // prover.rs:92
         if (!skip_b_g1) {                                                                                    // prover.rs:98-108
             RoctxRange rr("Compute B in G1");                                                                 // prover.rs:99
-            G16_TRY(run_pass(3, pk->b_g1, 0, pk->b_g1_count, sort_z, &buf_b1));
-            G16_TRY(heavy_early(3, buf_b1, sort_z));
-            jobs[njobs++] = {3, &buf_b1, &sort_z};
+            queue_pass(3, pk->b_g1, 0, pk->b_g1_count, sort_z, &buf_b1);
         }
+        if (!h_in_batch) G16_TRY(run_batch());
         // ---- h_acc = msm(h_query, h) (prover.rs:63-66): needs the witness map
         G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_h, 0));
-        last_end = nullptr;       // whatever stream 1 waits for here is not the h pass
+        if (!h_in_batch) last_end = nullptr;       // whatever stream 1 waits for here is not the h pass
         { RoctxRange rr("Compute C");                                                                        // prover.rs:62 (h_acc; l_acc above)
-        G16_TRY(run_pass(0, pk->h, 0, pk->h_count, sort_h, &buf_h)); }
-        G16_TRY(heavy_early(0, buf_h, sort_h));
-        jobs[njobs++] = {0, &buf_h, &sort_h};
+        queue_pass(0, pk->h, 0, pk->h_count, sort_h, &buf_h);
+        last_batch = true;
+        G16_TRY(run_batch()); }
         // the G1 reductions, batched by bucket layout (h's window size may differ from the witness MSMs')
         bool done[4] = {false, false, false, false};
         for (int i = 0; i < njobs; ++i) {
@@ -228,8 +292,13 @@ struct Prover {
                     bb[nb] = jobs[q].buf; sp[nb] = jobs[q].ss; idx[nb] = q; ++nb;
                     done[q] = true;
                 }
-            for (int q = 0; q < nb; ++q) G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_heavy[jobs[idx[q]].k], 0));
-            G16_TRY((msm_reduce_batch<Fq>(bb, sp, nb, s1, /*heavy_done=*/true)));
+            bool any_early = false;
+            for (int q = 0; q < nb; ++q) any_early = any_early || early[jobs[idx[q]].k];
+            for (int q = 0; q < nb; ++q) {
+                if (early[jobs[idx[q]].k]) G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_heavy[jobs[idx[q]].k], 0));
+                else if (any_early) G16_TRY((msm_heavy_reduce<Fq>(*bb[q], *sp[q], s1)));   // mixed group: this one's first stage here
+            }
+            G16_TRY((msm_reduce_batch<Fq>(bb, sp, nb, s1, /*heavy_done=*/any_early)));
             for (int q = 0; q < nb; ++q) G16_TRY(copy_out(jobs[idx[q]].k, *jobs[idx[q]].buf, *jobs[idx[q]].ss, s1));
         }
 
@@ -287,8 +356,13 @@ struct Prover {
         for (int i = 0; i < 5; ++i) {
             float t = 0.f;
             tm.bucket_ms[i] = (pass_begin[i] && pass_end[i] && hipEventElapsedTime(&t, pass_begin[i], pass_end[i]) == hipSuccess) ? (double)t : 0.0;
+            // MSMs that went as one launch share its interval: each gets the part its points are of the launch's
+            double wsum = 0.0;
+            for (int q = 0; q < 4; ++q) if (pass_begin[q] == pass_begin[i] && pass_end[q] == pass_end[i]) wsum += weight[q];
+            if (i < 4 && wsum > 0.0) tm.bucket_ms[i] *= weight[i] / wsum;
             tm.bucket_pass_ms += tm.bucket_ms[i];
         }
+        tm.g1_pass_launches = (double)g1_launches;
         tm.finish_ms = fold_ms;
         tm.total_ms = t_end - t_begin;
         tm.window_bits = sort_z.plan.c;

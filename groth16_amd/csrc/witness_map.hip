@@ -10,6 +10,7 @@
 //   h[k] = q[bitrev(k)] * n^-1 g^-k                           (coset ifft's tail, fused with the un-permute)
 // All kernels are HBM-streaming (32 B per element per sweep); the CSR mat-vec is gather-bound.
 #include "internal.hpp"
+#include <algorithm>
 #include <new>
 
 namespace g16 {
@@ -29,7 +30,7 @@ struct SpmvArgs {
 // (0, 1, n, 0).
 template <class Fr>
 __global__ void spmv3_kernel(SpmvArgs<Fr> args, const Fr* __restrict__ z, uint64_t num_inputs, uint64_t nc, uint64_t row0, uint64_t stride,
-                             uint64_t rows, int out_rev_bits) {
+                             uint64_t rows, int out_rev_bits, uint64_t out0) {
     const int m = blockIdx.y;
     const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= rows) return;
@@ -51,7 +52,7 @@ __global__ void spmv3_kernel(SpmvArgs<Fr> args, const Fr* __restrict__ z, uint64
     } else if (m == 0 && row - nc < num_inputs) {
         acc = z[row - nc];
     }
-    args.out[m][out_rev_bits ? (uint64_t)(__brev((uint32_t)li) >> (32 - out_rev_bits)) : li] = acc;
+    args.out[m][out0 + (out_rev_bits ? (uint64_t)(__brev((uint32_t)li) >> (32 - out_rev_bits)) : li)] = acc;
 }
 
 // a <- (a*b - c) * zinv
@@ -64,7 +65,7 @@ __global__ void quotient_kernel(Fr* __restrict__ a, const Fr* __restrict__ b, co
 
 template <class C>
 int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, typename C::Fr* d_h, Arena& arena, hipStream_t st,
-                       EventTimer* ntt_timers) {
+                       EventTimer* ntt_timers, ZUpload* up) {
     typedef typename C::Fr Fr;
     const Domain<C>* dom = ck->dom;
     const size_t n = dom->n;
@@ -80,9 +81,43 @@ int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, ty
         args.val[m] = ck->val[m];
         args.out[m] = outs[m];
     }
-    hipLaunchKernelGGL((spmv3_kernel<Fr>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, st, args, d_z, ck->num_inputs,
-                       ck->num_constraints, (uint64_t)0, (uint64_t)1, (uint64_t)n, 0);
-    G16_LAUNCH_CHECK();
+    if (!up) {
+        hipLaunchKernelGGL((spmv3_kernel<Fr>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, st, args, d_z, ck->num_inputs,
+                           ck->num_constraints, (uint64_t)0, (uint64_t)1, (uint64_t)n, 0, (uint64_t)0);
+        G16_LAUNCH_CHECK();
+    } else {
+        // The assignment is still on the host (full_assignment: &[F], prover.rs:33).  Everything after the mat-vec needs all of a, b, c,
+        // but the mat-vec itself does not need all of z: piece by piece on the copy stream, and after each piece the row blocks it
+        // unlocks (need_col, computed at load time: circuits allocate their variables as they emit constraints, so row block k
+        // mostly reads piece <= k -- exactly so for the benchmark's product chain; a circuit whose first row reads the last variable
+        // simply gets no overlap).  Saves the mat-vec's 0.65 ms of the 2.75 ms a 128 MiB upload costs at 2^22; the rest of the proof
+        // cannot start before the last byte has landed.
+        constexpr int ZC = DeviceCircuit<C>::Z_CHUNKS;
+        const uint64_t nz = ck->num_variables;
+        const int pieces = (int)std::min<uint64_t>(ZC, std::max<uint64_t>(1, nz >> 16));   // >= 2 MiB per piece
+        up->pieces = pieces;
+        const uint64_t per = (nz + pieces - 1) / pieces;
+        int next_block = 0;
+        for (int k = 0; k < pieces; ++k) {
+            const uint64_t lo = per * k, hi = std::min(nz, per * (k + 1));
+            if (hi > lo)
+                G16_HIP_TRY(hipMemcpyAsync(const_cast<Fr*>(d_z) + lo, static_cast<const Fr*>(up->host) + lo, (hi - lo) * sizeof(Fr),
+                                           hipMemcpyHostToDevice, up->copy_stream));
+            G16_HIP_TRY(hipEventRecord(up->landed[k], up->copy_stream));
+            int last_block = next_block;
+            while (last_block < ZC && (k == pieces - 1 || ck->need_col[last_block] < hi)) ++last_block;
+            if (last_block > next_block) {
+                const uint64_t r_lo = n * (uint64_t)next_block / ZC, r_hi = n * (uint64_t)last_block / ZC;
+                G16_HIP_TRY(hipStreamWaitEvent(st, up->landed[k], 0));
+                if (r_hi > r_lo) {
+                    hipLaunchKernelGGL((spmv3_kernel<Fr>), dim3((unsigned)((r_hi - r_lo + 255) / 256), 3), dim3(256), 0, st, args, d_z, ck->num_inputs,
+                                       ck->num_constraints, r_lo, (uint64_t)1, r_hi - r_lo, 0, r_lo);
+                    G16_LAUNCH_CHECK();
+                }
+                next_block = last_block;
+            }
+        }
+    }
     // ntt_timers (optional, two of them): the six transforms of :201-207,220-221, then the seventh (:232) with its un-permute
     if (ntt_timers) G16_TRY(ntt_timers[0].start(st));
     // ifft then coset fft of a, b, c (r1cs_to_qap.rs:201-207, 220-221): inverse DIF, n^-1 g^bitrev(i), forward DIT -- the three
@@ -249,7 +284,7 @@ int dwm_stage(const DeviceCircuit<C>* ck, const DistWm<C>* d, int stage, const t
             args.out[m] = work[m];
         }
         hipLaunchKernelGGL((spmv3_kernel<Fr>), dim3((unsigned)((M + 255) / 256), 3), dim3(256), 0, st, args, d_z, ck->num_inputs,
-                           ck->num_constraints, (uint64_t)d->rank, (uint64_t)d->world, (uint64_t)M, dm->log_n);
+                           ck->num_constraints, (uint64_t)d->rank, (uint64_t)d->world, (uint64_t)M, dm->log_n, (uint64_t)0);
         G16_LAUNCH_CHECK();
         G16_TRY((ntt_dit_batch<C>(dm, work, 3, /*inverse=*/true, nullptr, st)));
         for (int m = 0; m < 3; ++m) G16_TRY((scale_by_table<C>(work[m], d->tw1, M, st)));
@@ -308,7 +343,7 @@ int mark_unit_coefficients(DeviceCircuit<C>* ck, hipStream_t st) {
 template int mark_unit_coefficients<Bls12_381>(DeviceCircuit<Bls12_381>*, hipStream_t);
 template int mark_unit_coefficients<Bn254>(DeviceCircuit<Bn254>*, hipStream_t);
 
-template int witness_map_device<Bls12_381>(const DeviceCircuit<Bls12_381>*, const Bls12_381::Fr*, Bls12_381::Fr*, Arena&, hipStream_t, EventTimer*);
-template int witness_map_device<Bn254>(const DeviceCircuit<Bn254>*, const Bn254::Fr*, Bn254::Fr*, Arena&, hipStream_t, EventTimer*);
+template int witness_map_device<Bls12_381>(const DeviceCircuit<Bls12_381>*, const Bls12_381::Fr*, Bls12_381::Fr*, Arena&, hipStream_t, EventTimer*, ZUpload*);
+template int witness_map_device<Bn254>(const DeviceCircuit<Bn254>*, const Bn254::Fr*, Bn254::Fr*, Arena&, hipStream_t, EventTimer*, ZUpload*);
 
 }  // namespace g16

@@ -52,7 +52,8 @@ typedef enum {
     G16_ERR_NO_DEVICE = 6,
     G16_ERR_INTERNAL = 7,
     G16_ERR_UNEXPECTED_IDENTITY = 8, /* SynthesisError::UnexpectedIdentity: gamma or delta is zero (generator.rs:110-111) */
-    G16_ERR_INVALID_DATA = 9         /* SerializationError::InvalidData: bytes that are not a point of the group        */
+    G16_ERR_INVALID_DATA = 9,        /* SerializationError::InvalidData: bytes that are not a point of the group        */
+    G16_ERR_NO_PEER_ACCESS = 10      /* g16_ctx_create_multi with G16_MULTI_REQUIRE_PEER=1: a device pair without peer access */
 } g16_status;
 
 typedef enum { G16_BLS12_381 = 0, G16_BN254 = 1 } g16_curve;
@@ -125,11 +126,13 @@ typedef struct {
     double finish_ms;      /* host glue: scalar muls, final adds, into_affine */
     double total_ms;
     double bucket_pass_ms; /* sum over the 5 MSMs of the bucket-accumulation kernel */
-    double bucket_ms[5];   /* that kernel per MSM: h, l, a, b_g1 (G1 kernel), b_g2 (G2 kernel); HIP events on the ctx stream */
+    double bucket_ms[5];   /* that kernel per MSM: h, l, a, b_g1 (G1 kernel), b_g2 (G2 kernel); HIP events on the ctx stream (see g1_pass_launches) */
     double window_bits;    /* Pippenger window size c of the witness MSMs in the last call ... */
     double windows;        /* ... and their window count W: a bucket pass folds (bases in the shard) * W points */
     double ntt_ms;         /* the seven transforms of r1cs_to_qap.rs:201-232 alone (inside witness_map_ms, which also covers
                               the three sparse mat-vecs and the pointwise pass) */
+    double g1_pass_launches; /* launches of the G1 bucket kernel in the last call: MSMs that are ready together share ONE launch
+                              (l, a, b_g1; h too in a sharded proof), bucket_ms[] then holds each one's share of it by points */
 } g16_timings;
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out);
@@ -149,6 +152,10 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out);
  * The process-per-GPU form (g16_prove_partial + one all-gather, bench.py --gpus N) is the supported multi-GPU path. */
 int g16_ctx_create_multi(int curve, const int* device_ids, int n_dev, g16_ctx** out);
 int g16_ctx_num_devices(const g16_ctx* ctx);
+/* 1: device i of the context reaches device j's memory directly (hipDeviceCanAccessPeer said yes and the access was enabled, or
+ * i and j are the same physical device); 0: copies between the two are staged through host memory by the runtime (correct, slow --
+ * G16_MULTI_REQUIRE_PEER=1 makes g16_ctx_create_multi fail with G16_ERR_NO_PEER_ACCESS instead); -1: bad index. */
+int g16_ctx_peer_access(const g16_ctx* ctx, int i, int j);
 void g16_ctx_destroy(g16_ctx* ctx);
 /* HIP stream the ctx launches on (hipStream_t); lets callers bracket work with their own events */
 void* g16_ctx_stream(g16_ctx* ctx);

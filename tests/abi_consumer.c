@@ -35,8 +35,13 @@ static void layouts(void) {
     FIELD(g16_timings, witness_map_ms); FIELD(g16_timings, msm_h_ms); FIELD(g16_timings, msm_l_ms); FIELD(g16_timings, msm_a_ms);
     FIELD(g16_timings, msm_b_g1_ms); FIELD(g16_timings, msm_b_g2_ms); FIELD(g16_timings, scalar_prep_ms); FIELD(g16_timings, finish_ms);
     FIELD(g16_timings, total_ms); FIELD(g16_timings, bucket_pass_ms); FIELD(g16_timings, bucket_ms); FIELD(g16_timings, window_bits);
-    FIELD(g16_timings, windows); FIELD(g16_timings, ntt_ms);
+    FIELD(g16_timings, windows); FIELD(g16_timings, ntt_ms); FIELD(g16_timings, g1_pass_launches);
     END(g16_timings);
+    BEGIN(g16_pk_info);
+    FIELD(g16_pk_info, window_bits_z); FIELD(g16_pk_info, window_bits_h); FIELD(g16_pk_info, table_fallback);
+    FIELD(g16_pk_info, bucket_shard_rank); FIELD(g16_pk_info, bucket_shard_world); FIELD(g16_pk_info, n_devices);
+    FIELD(g16_pk_info, device_bytes);
+    END(g16_pk_info);
     BEGIN(g16_diag);
     FIELD(g16_diag, mad_per_s); FIELD(g16_diag, mads_per_add_g1); FIELD(g16_diag, mads_per_add_g2); FIELD(g16_diag, mads_per_product);
     FIELD(g16_diag, limbs);

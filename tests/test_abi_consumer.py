@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MIRRORS = {
     "g16_query": b.QueryC, "g16_pk_view": b.PkViewC, "g16_csr_view": b.CsrViewC, "g16_proof": b.ProofC, "g16_partial": b.PartialC,
     "g16_timings": b.TimingsC, "g16_diag": b.DiagC, "g16_toxic_waste": b.ToxicWasteC, "g16_params_view": b.ParamsViewC,
+    "g16_pk_info": b.PkInfoC,
 }
 
 

@@ -295,6 +295,16 @@ def test_proof_bucket_schemes(env, orc, g, scheme, monkeypatch):
     gp = pk_of(g, pk)
     parts = [prover.prove_partial(gp, gm, ck.z, (i, 3)) for i in range(3)]
     assert (prover.prove_finalize(gp, ck.num_inputs, parts, r, s, (0, 3)).flat() == want).all()
+    # the key says how it is held -- and WHY, when it is the slower plain-bases form (g16_pk_get_info.table_fallback)
+    info = prover.pk_info(gp, ck.num_inputs, (1, 3))
+    if scheme.get("G16_MSM_PRECOMP") == "0":
+        assert info["table_fallback"] == 1 and info["window_bits_z"] == 0, info
+    elif "G16_PK_TABLE_BUDGET_MB" in scheme:
+        whole = prover.pk_info(gp, ck.num_inputs)
+        assert whole["table_fallback"] == 3 and whole["window_bits_z"] == 0 and "did not fit" in whole["held_as"], whole
+    else:
+        assert info["table_fallback"] == 0 and info["window_bits_z"] == int(scheme.get("G16_MSM_PRECOMP_WINDOW", info["window_bits_z"])), info
+        assert info["device_bytes"] > 0 and info["bucket_shard_world"] == 1
 
 
 def test_proof_golden_pymodel(env, orc, g):
@@ -420,6 +430,31 @@ def test_multi_device_context_distinct_gpus(orc, g, curve):
             for r, s in ((orc.rand_fr(curve, 91, 1)[0], orc.rand_fr(curve, 92, 1)[0]), (np.zeros(4, dtype=np.uint64), orc.rand_fr(curve, 93, 1)[0])):
                 proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
                 assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+
+
+def test_multi_device_context_peer_access_refusal(orc, g, monkeypatch):
+    """g16_ctx_create_multi probes peer access per device pair instead of assuming it.  One physical GPU listed twice has no
+    distinct pair, so the refusal is injected (G16_MULTI_FAKE_NO_PEER=1): with G16_MULTI_REQUIRE_PEER=1 the context is REFUSED with
+    its own status (10, G16_ERR_NO_PEER_ACCESS) -- a loud failure instead of a slow prover; without it the context comes up, reports
+    the pair as host-staged (g16_ctx_peer_access == 0) and still proves correctly."""
+    curve = "bn254"
+    ck = orc.syn_circuit(curve, 8, 6)
+    pk, _ = orc.setup(ck, 4)
+    gm, gp = mats_of(g, ck), pk_of(g, pk)
+    r, s = orc.rand_fr(curve, 91, 1)[0], orc.rand_fr(curve, 92, 1)[0]
+    with g.Groth16(curve, [0, 0]) as prover:   # same physical device twice: "direct" by definition
+        lb = prover._ctx.lib
+        assert lb.c.g16_ctx_peer_access(prover._ctx.handle, 0, 1) == 1 and lb.c.g16_ctx_peer_access(prover._ctx.handle, 0, 2) == -1
+    monkeypatch.setenv("G16_MULTI_FAKE_NO_PEER", "1")
+    with g.Groth16(curve, [0, 0]) as prover:
+        lb = prover._ctx.lib
+        assert lb.c.g16_ctx_peer_access(prover._ctx.handle, 0, 1) == 0 and lb.c.g16_ctx_peer_access(prover._ctx.handle, 1, 1) == 1
+        proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
+        assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
+    monkeypatch.setenv("G16_MULTI_REQUIRE_PEER", "1")
+    with pytest.raises(g.G16Error) as ei:
+        g.Groth16(curve, [0, 0])
+    assert ei.value.status == 10 and "no peer access" in str(ei.value)
 
 
 def test_multi_device_context_padded_domain(orc, g):

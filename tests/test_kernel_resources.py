@@ -71,7 +71,7 @@ def test_reductions_keep_two_waves_per_simd_and_nothing_in_scratch(kernels):
     """the three reduction kernels, G1 and lane-pair G2.  Round 3: the G2 ones needed 376 + 120 registers (ONE wave per SIMD, and no
     bucket-pass wave beside them) and bucket_reduce_kernel<Fp30> spilled 144 B.  Round 4: they add with acc_add_streamed (both operands
     behind stores, coordinates fetched where they are consumed): every one of the six must fit two waves per SIMD with no scratch."""
-    for sub in ("bucket_reduce_kernel<", "window_reduce_kernel<", "heavy_reduce_kernel<"):
+    for sub in ("bucket_reduce_kernel<", "window_reduce_kernel<", "heavy_reduce_kernel<", "bucket_combine_kernel<"):
         for field in ("Fp30<", "Fp2p30<"):
             for name, k in pick(kernels, sub, field).items():
                 assert k["waves_per_simd"] >= 2, (name, k)
