@@ -439,7 +439,7 @@ def projected_scaling(p, single_ms, steps, dist_wm_ok):
         for n_ranks in (2, 4, 8):
             try:
                 ranks = tuple(range(n_ranks)) if mode == "bucket" else (0,)
-                sh = sim_share(p, n_ranks, mode, max(2, min(steps, 4)), 1, dist_wm_ok(n_ranks, p.k), ranks)
+                sh = sim_share(p, n_ranks, mode, max(2, min(steps, 4)), 2, dist_wm_ok(n_ranks, p.k), ranks)
                 share = sh["partial_ms"] + sh["finalize_ms"]
                 out["points"].append(dict(n_gpus=n_ranks, shard_mode=mode, rank_share_ms=round(share, 3), partial_ms=round(sh["partial_ms"], 3),
                                           finalize_ms=round(sh["finalize_ms"], 3), projected_speedup=round(single_ms / share, 3),

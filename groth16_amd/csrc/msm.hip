@@ -1091,7 +1091,11 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
         return G16_OK;
     };
     // merged plan: ~2048 workgroups over the class regions (a class region may hold anything between nothing and all entries)
-    unsigned gx = std::max(1u, std::min(2048u / Q, (unsigned)((nw + SORT_THREADS - 1) / SORT_THREADS)));
+    // ... but at most 256 per class: every workgroup zeroes, scans and flushes a 2^15-counter histogram whatever it counts, and with
+    // the few classes of a sharded proof (bucket-space shard at 2^22 / 8: 2 classes, 3.4 M entries each) 1024 workgroups per class spent
+    // more time on that than on their 3 300 entries (rank share 10.79 -> 10.32 - 10.41 ms at 128 / 256, same box; whole keys have 16
+    // classes, 128 workgroups each, and do not change)
+    unsigned gx = std::max(1u, std::min(std::min(2048u / Q, 256u), (unsigned)((nw + SORT_THREADS - 1) / SORT_THREADS)));
     if (const char* e = getenv("G16_SORT_GX")) {   // experiments: workgroups per class of the merged counting sort
         const int v = atoi(e);
         if (v >= 1 && v <= 4096) gx = (unsigned)v;

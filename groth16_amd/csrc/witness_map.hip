@@ -90,20 +90,26 @@ int witness_map_device(const DeviceCircuit<C>* ck, const typename C::Fr* d_z, ty
         // but the mat-vec itself does not need all of z: piece by piece on the copy stream, and after each piece the row blocks it
         // unlocks (need_col, computed at load time: circuits allocate their variables as they emit constraints, so row block k
         // mostly reads piece <= k -- exactly so for the benchmark's product chain; a circuit whose first row reads the last variable
-        // simply gets no overlap).  Saves the mat-vec's 0.65 ms of the 2.75 ms a 128 MiB upload costs at 2^22; the rest of the proof
-        // cannot start before the last byte has landed.
+        // simply gets no overlap).  Hides most of the mat-vec (0.44 ms at 2^22) behind the 2.4 ms a 128 MiB upload takes at 55 GB/s; the
+        // rest of the proof -- every transform needs all of a, b, c, every sort all of z -- cannot start before the last byte has landed.
         constexpr int ZC = DeviceCircuit<C>::Z_CHUNKS;
         const uint64_t nz = ck->num_variables;
-        const int pieces = (int)std::min<uint64_t>(ZC, std::max<uint64_t>(1, nz >> 16));   // >= 2 MiB per piece
+        const int pieces = (int)std::min<uint64_t>(4, std::max<uint64_t>(1, nz >> 16));   // >= 2 MiB per piece; four of them
         up->pieces = pieces;
         const uint64_t per = (nz + pieces - 1) / pieces;
-        int next_block = 0;
+        // all the copies first, back to back (pinned memory: each call returns at once, the pieces follow each other on the copy
+        // engine with ~10 us between them; enqueued in turn with the launches they unlock the host's ~45 us per round of calls sat
+        // BETWEEN the copies and cost more than the overlap gave -- kernel + copy trace of round 5, profiles/r05_upload_timeline.txt)
         for (int k = 0; k < pieces; ++k) {
             const uint64_t lo = per * k, hi = std::min(nz, per * (k + 1));
             if (hi > lo)
                 G16_HIP_TRY(hipMemcpyAsync(const_cast<Fr*>(d_z) + lo, static_cast<const Fr*>(up->host) + lo, (hi - lo) * sizeof(Fr),
                                            hipMemcpyHostToDevice, up->copy_stream));
             G16_HIP_TRY(hipEventRecord(up->landed[k], up->copy_stream));
+        }
+        int next_block = 0;
+        for (int k = 0; k < pieces; ++k) {
+            const uint64_t hi = std::min(nz, per * (k + 1));
             int last_block = next_block;
             while (last_block < ZC && (k == pieces - 1 || ck->need_col[last_block] < hi)) ++last_block;
             if (last_block > next_block) {
