@@ -270,6 +270,7 @@ template <class F> int msm_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss
 // heavy_done: the heavy-bucket combines already ran (msm_heavy_reduce, one MSM at a time underneath the following pass)
 template <class F> int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st, bool heavy_done);
 template <class F> int msm_heavy_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st);
+template <class F> int msm_heavy_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st);
 // MSM bases are kept on the device in the bucket kernel's own Montgomery radix (x*R' with R' = 2^(30 NL), canonical,
 // packed in the usual words): converted in place, once, after upload (F = Fq for G1, Fq2 for G2).
 template <class F> int convert_bases(Affine<F>* d_bases, uint64_t n, hipStream_t st);

@@ -139,7 +139,15 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const
 //                           the class region instead of a digit plane.   Sorted entry = point | window << 26 | sign << 31.
 // ---------------------------------------------------------------------------------------------
 static constexpr int CLASS_THREADS = 256;
-static constexpr int MAX_CLASSES = 16;
+static constexpr int MAX_CLASSES = 64;
+// The merged counting sort works on SORT CLASSES of 2^13 buckets (round 5; 2^15 before) with 256-lane workgroups: a 32 KB histogram and
+// four waves (<= 32 registers each) fit on a compute unit BESIDE eight bucket-pass workgroups (8 x 13 KB of LDS, 2 x 190 / 2 x 239 of a
+// SIMD's 512 registers), so h's sort -- which cannot start before the witness map ends, i.e. when the passes begin -- runs underneath the
+// passes instead of waiting for a kernel boundary: with 128 KB histograms its count and scatter kernels each sat out a whole 23 ms
+// pass and the h pass then waited 2.3 ms for the scatter (kernel trace of round 5).  The sorted list does not depend on the class
+// size (classes are contiguous bucket ranges); the reductions keep their own grouping (MsmPlan::B, groups).
+static constexpr uint32_t SORT_CLASS_LOG = 13;
+static constexpr int SORT_M_THREADS = 256;
 
 // the thread's scalar, biased, as little-endian words in its column of sw
 template <class Fr>
@@ -201,48 +209,62 @@ __global__ __launch_bounds__(CLASS_THREADS) void class_partition_kernel(const Fr
     }
 }
 
-// grid = (G, Q): workgroup (x, q) owns the tiles x, x + G, x + 2G, ... (SORT_THREADS entries each) of class region q
-static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_merged_kernel(const uint16_t* __restrict__ ent_key,
+// grid = (G, Q): workgroup (x, q) owns the tiles x, x + G, x + 2G, ... (SORT_M_THREADS entries each) of class region q.
+// NO global atomics (round 5).  The first version flushed every workgroup's histogram with one global atomic per non-empty bucket and
+// reserved scatter slices with one RETURNING global atomic per non-empty bucket: 2048 workgroups x ~18 000 buckets = 37 M device-scope
+// atomics per kernel at 2^22 -- on this GPU those are performed at the memory side (eight XCDs, eight L2s) -- 0.9 ms for the count and
+// 2.5 ms for the scatter of a 54.5 M-entry sort whose compulsory traffic is ~1.3 GB.  Now each workgroup STORES its histogram as one
+// row of a [class][workgroup][bucket] matrix (coalesced), a small kernel turns the columns into exclusive prefixes over the
+// workgroups (one thread per bucket, coalesced across threads) and totals, and the scatter reads its row back: its slice of bucket b
+// starts at offsets[b] + prefix[workgroup][b].  The scatter no longer re-counts its tiles either.
+static __global__ __launch_bounds__(SORT_M_THREADS) void bucket_count_merged_kernel(const uint16_t* __restrict__ ent_key,
                                                                            const uint32_t* __restrict__ class_off, uint32_t nb, uint32_t B,
-                                                                           uint32_t* __restrict__ counts) {
+                                                                           uint32_t* __restrict__ wg_counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     const uint32_t q = blockIdx.y;
     const uint32_t lo = class_off[(uint64_t)q * nb], hi = class_off[(uint64_t)(q + 1) * nb];
-    if ((uint64_t)lo + (uint64_t)blockIdx.x * SORT_THREADS >= hi) return;
-    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) hist[b] = 0;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_M_THREADS) hist[b] = 0;
     __syncthreads();
-    for (uint64_t p = (uint64_t)lo + blockIdx.x * SORT_THREADS + threadIdx.x; p < hi; p += (uint64_t)gridDim.x * SORT_THREADS)
+    for (uint64_t p = (uint64_t)lo + blockIdx.x * SORT_M_THREADS + threadIdx.x; p < hi; p += (uint64_t)gridDim.x * SORT_M_THREADS)
         atomicAdd(&hist[ent_key[p] & 0x7fffu], 1u);
     __syncthreads();
-    uint32_t* out = counts + (uint64_t)q * B;
-    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
-        const uint32_t v = hist[b];
-        if (v) atomicAdd(&out[b], v);
-    }
+    uint32_t* out = wg_counts + ((uint64_t)q * gridDim.x + blockIdx.x) * B;   // a workgroup without tiles stores its row of zeros
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_M_THREADS) out[b] = hist[b];
 }
 
-static __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_merged_kernel(const uint16_t* __restrict__ ent_key,
+// one thread per (class, bucket): wg_counts[q][x][b] <- sum of the rows x' < x (in place), counts[q * B + b] <- the column's total
+static __global__ __launch_bounds__(256) void bucket_wg_scan_kernel(uint32_t* __restrict__ wg_counts, uint32_t G, uint32_t B, uint32_t M,
+                                                                    uint32_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t q = i / B, b = i - q * B;
+    uint32_t* col = wg_counts + (uint64_t)q * G * B + b;
+    uint32_t run = 0;
+    for (uint32_t x = 0; x < G; ++x) {
+        const uint32_t v = col[(uint64_t)x * B];
+        col[(uint64_t)x * B] = run;
+        run += v;
+    }
+    counts[i] = run;
+}
+
+static __global__ __launch_bounds__(SORT_M_THREADS) void bucket_scatter_merged_kernel(const uint16_t* __restrict__ ent_key,
                                                                              const uint32_t* __restrict__ ent_tag,
                                                                              const uint32_t* __restrict__ class_off, uint32_t nb, uint32_t B,
-                                                                             const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
-                                                                             uint32_t* __restrict__ sorted) {
+                                                                             const uint32_t* __restrict__ offsets,
+                                                                             const uint32_t* __restrict__ wg_counts, uint32_t* __restrict__ sorted) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     const uint32_t q = blockIdx.y;
     const uint32_t lo = class_off[(uint64_t)q * nb], hi = class_off[(uint64_t)(q + 1) * nb];
-    if ((uint64_t)lo + (uint64_t)blockIdx.x * SORT_THREADS >= hi) return;
-    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) hist[b] = 0;
-    __syncthreads();
-    const uint64_t first = (uint64_t)lo + blockIdx.x * SORT_THREADS + threadIdx.x, step = (uint64_t)gridDim.x * SORT_THREADS;
-    for (uint64_t p = first; p < hi; p += step) atomicAdd(&hist[ent_key[p] & 0x7fffu], 1u);
-    __syncthreads();
+    if ((uint64_t)lo + (uint64_t)blockIdx.x * SORT_M_THREADS >= hi) return;
+    // hist[b] = this workgroup's write cursor in bucket b: the bucket's offset + what the workgroups before this one put there
     const uint64_t qb = (uint64_t)q * B;
-    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
-        const uint32_t v = hist[b];
-        if (v) hist[b] = offsets[qb + b] + atomicAdd(&cursor[qb + b], v);
-    }
+    const uint32_t* mine = wg_counts + ((uint64_t)q * gridDim.x + blockIdx.x) * B;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_M_THREADS) hist[b] = offsets[qb + b] + mine[b];
     __syncthreads();
+    const uint64_t first = (uint64_t)lo + blockIdx.x * SORT_M_THREADS + threadIdx.x, step = (uint64_t)gridDim.x * SORT_M_THREADS;
     for (uint64_t p = first; p < hi; p += step) {
         const uint32_t d = ent_key[p];
         const uint32_t pos = atomicAdd(&hist[d & 0x7fffu], 1u);
@@ -1029,7 +1051,15 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     uint32_t* ent_tag = nullptr;    // merged plan: entry tags (point | window << 26), class-partitioned
     uint32_t *class_cnt = nullptr, *class_off = nullptr;
     uint32_t *counts = nullptr, *cursor = nullptr, *nparts = nullptr, *block_sums = nullptr;
-    const uint32_t nb = (uint32_t)((n + CLASS_THREADS - 1) / CLASS_THREADS), Q = (uint32_t)plan.groups;
+    // merged plan: sort classes of Bs = 2^13 buckets (or the whole bucket set when it is smaller)
+    uint32_t sort_class_log = SORT_CLASS_LOG;
+    if (const char* e = getenv("G16_SORT_CLASS_LOG")) {   // A/B: 15 = histograms of 128 KB (no room beside the bucket passes)
+        const int v = atoi(e);
+        if (v >= 8 && v <= 15) sort_class_log = (uint32_t)v;
+    }
+    const uint32_t slog = plan.merged ? std::min<uint32_t>(sort_class_log, (uint32_t)ilog2(plan.B)) : 0u;
+    const uint32_t Bs = plan.merged ? 1u << slog : plan.B;
+    const uint32_t nb = (uint32_t)((n + CLASS_THREADS - 1) / CLASS_THREADS), Q = plan.merged ? M >> slog : (uint32_t)plan.groups;
     G16_TRY(arena.alloc_n(nw ? nw : 1, &planes));
     if (plan.merged) {
         if (Q > MAX_CLASSES) return G16_ERR_INTERNAL;
@@ -1062,7 +1092,7 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     pd.shard_n = (uint32_t)plan.shard_n;
     pd.shard_r = (uint32_t)plan.shard_r;
     pd.shard_magic = plan.shard_n > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)plan.shard_n - 1) / (uint64_t)plan.shard_n) : 0u;
-    const size_t lds = (size_t)plan.B * sizeof(uint32_t);
+    const size_t lds = (size_t)Bs * sizeof(uint32_t);
     static PerDeviceOnce attr_once;
     std::atomic<bool>& attr_set = attr_once.flag();
     if (!attr_set) {
@@ -1077,7 +1107,7 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
         attr_set = true;
     }
     const unsigned nchunks = (unsigned)((n + plan.chunk - 1) / plan.chunk);
-    const uint32_t blog = (uint32_t)ilog2(plan.B);
+    const uint32_t blog = plan.merged ? slog : (uint32_t)ilog2(plan.B);
     const uint32_t max_scan = std::max(M, plan.merged ? Q * nb : 0u);
     G16_TRY(arena.alloc_n((size_t)(max_scan + SCAN_TILE - 1) / SCAN_TILE, &block_sums));
     auto prefix_scan = [&](const uint32_t* vals, uint32_t* prefix, uint32_t count, uint32_t padmask = 0) -> int {
@@ -1090,16 +1120,15 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
         G16_LAUNCH_CHECK();
         return G16_OK;
     };
-    // merged plan: ~2048 workgroups over the class regions (a class region may hold anything between nothing and all entries)
-    // ... but at most 256 per class: every workgroup zeroes, scans and flushes a 2^15-counter histogram whatever it counts, and with
-    // the few classes of a sharded proof (bucket-space shard at 2^22 / 8: 2 classes, 3.4 M entries each) 1024 workgroups per class spent
-    // more time on that than on their 3 300 entries (rank share 10.79 -> 10.32 - 10.41 ms at 128 / 256, same box; whole keys have 16
-    // classes, 128 workgroups each, and do not change)
-    unsigned gx = std::max(1u, std::min(std::min(2048u / Q, 256u), (unsigned)((nw + SORT_THREADS - 1) / SORT_THREADS)));
+    // merged plan: ~4096 workgroups of 256 lanes over the class regions (a class region may hold anything between nothing and all
+    // entries), at most 256 per class: every workgroup zeroes, stores and re-reads a histogram row whatever it counts
+    unsigned gx = std::max(1u, std::min(std::min(4096u / Q, 256u), (unsigned)((nw + SORT_M_THREADS - 1) / SORT_M_THREADS)));
     if (const char* e = getenv("G16_SORT_GX")) {   // experiments: workgroups per class of the merged counting sort
         const int v = atoi(e);
         if (v >= 1 && v <= 4096) gx = (unsigned)v;
     }
+    uint32_t* wg_counts = nullptr;   // merged plan: [class][workgroup][bucket] histograms, then their prefixes over the workgroups
+    if (plan.merged) G16_TRY(arena.alloc_n((size_t)Q * gx * Bs, &wg_counts));
     if (n) {
         if (plan.merged) {
             hipLaunchKernelGGL((class_count_kernel<Fr>), dim3(nb), dim3(CLASS_THREADS), 0, st, d_scalars, n, pd, blog, Q, class_cnt);
@@ -1108,7 +1137,9 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
             hipLaunchKernelGGL((class_partition_kernel<Fr>), dim3(nb), dim3(CLASS_THREADS), 0, st, d_scalars, n, pd, blog, Q, class_off, planes,
                                ent_tag);
             G16_LAUNCH_CHECK();
-            hipLaunchKernelGGL(bucket_count_merged_kernel, dim3(gx, Q), dim3(SORT_THREADS), lds, st, planes, class_off, nb, plan.B, counts);
+            hipLaunchKernelGGL(bucket_count_merged_kernel, dim3(gx, Q), dim3(SORT_M_THREADS), lds, st, planes, class_off, nb, Bs, wg_counts);
+            G16_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bucket_wg_scan_kernel, dim3((M + 255) / 256), dim3(256), 0, st, wg_counts, gx, Bs, M, counts);
         } else {
             hipLaunchKernelGGL((digits_kernel<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pd, planes);
             G16_LAUNCH_CHECK();
@@ -1124,8 +1155,8 @@ int sort_scalars(const typename C::Fr* d_scalars, uint64_t n, int merged_c, Aren
     G16_TRY(prefix_scan(nparts, out->task_off, M));
     if (n) {
         if (plan.merged)
-            hipLaunchKernelGGL(bucket_scatter_merged_kernel, dim3(gx, Q), dim3(SORT_THREADS), lds, st, planes, ent_tag, class_off, nb, plan.B,
-                               out->offsets, cursor, out->sorted);
+            hipLaunchKernelGGL(bucket_scatter_merged_kernel, dim3(gx, Q), dim3(SORT_M_THREADS), lds, st, planes, ent_tag, class_off, nb, Bs,
+                               out->offsets, wg_counts, out->sorted);
         else
             hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nchunks, plan.W), dim3(SORT_THREADS), lds, st, planes, n, plan.chunk, plan.c, plan.B,
                                out->offsets, cursor, out->sorted);
@@ -1287,20 +1318,30 @@ static ReduceBatch<AccRaw<typename Lazy30<F>::type::Raw>, XYZZ<F>> make_reduce_b
 
 // the cooperative combine of one MSM's heavy buckets alone (a few hundred workgroups at most: cheap enough to run underneath
 // the next bucket pass, which takes it off the batched reduction's chain)
+// (n MSMs with one bucket layout: one launch per kernel)
 template <class F>
-int msm_heavy_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
+int msm_heavy_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* sorts, int n, hipStream_t st) {
     typedef typename Lazy30<F>::type F30;
+    if (n < 1 || n > REDUCE_BATCH) return G16_ERR_INTERNAL;
+    const MsmPlan& plan = sorts[0]->plan;
+    for (int i = 1; i < n; ++i)
+        if (sorts[i]->plan.B != plan.B || sorts[i]->plan.groups != plan.groups) return G16_ERR_INTERNAL;
     size_t lds_heavy, lds_win;
     G16_TRY(reduce_setup<F>(&lds_heavy, &lds_win));
-    const MsmBuffers<F>* b = &buf;
-    const ScalarSort* s = &ss;
-    const auto batch = make_reduce_batch<F>(&b, &s, 1);
-    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, 1), dim3(HEAVY_THREADS), lds_heavy, st, batch);
+    const auto batch = make_reduce_batch<F>(bufs, sorts, n);
+    hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, n), dim3(HEAVY_THREADS), lds_heavy, st, batch);
     G16_LAUNCH_CHECK();
-    const uint32_t M = ss.plan.buckets();
-    hipLaunchKernelGGL((bucket_combine_kernel<F30>), dim3((M * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, 1), dim3(RED_THREADS), 0, st, batch, M);
+    const uint32_t M = plan.buckets();
+    hipLaunchKernelGGL((bucket_combine_kernel<F30>), dim3((M * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, n), dim3(RED_THREADS), 0, st, batch, M);
     G16_LAUNCH_CHECK();
     return G16_OK;
+}
+
+template <class F>
+int msm_heavy_reduce(const MsmBuffers<F>& buf, const ScalarSort& ss, hipStream_t st) {
+    const MsmBuffers<F>* b = &buf;
+    const ScalarSort* s = &ss;
+    return msm_heavy_reduce_batch<F>(&b, &s, 1, st);
 }
 
 template <class F>
@@ -1315,13 +1356,7 @@ int msm_reduce_batch(const MsmBuffers<F>* const* bufs, const ScalarSort* const* 
     size_t lds_heavy, lds_win;
     G16_TRY(reduce_setup<F>(&lds_heavy, &lds_win));
     const auto batch = make_reduce_batch<F>(bufs, sorts, n);
-    if (!heavy_done) {
-        hipLaunchKernelGGL((heavy_reduce_kernel<F30>), dim3(HEAVY_BLOCKS, n), dim3(HEAVY_THREADS), lds_heavy, st, batch);
-        G16_LAUNCH_CHECK();
-        const uint32_t M = plan.buckets();
-        hipLaunchKernelGGL((bucket_combine_kernel<F30>), dim3((M * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, n), dim3(RED_THREADS), 0, st, batch, M);
-        G16_LAUNCH_CHECK();
-    }
+    if (!heavy_done) G16_TRY((msm_heavy_reduce_batch<F>(bufs, sorts, n, st)));
     hipLaunchKernelGGL((bucket_reduce_kernel<F30>), dim3((cpw * plan.groups * F30::LANES_PER_TASK + RED_THREADS - 1) / RED_THREADS, n), dim3(RED_THREADS), 0,
                        st, batch, plan.B, plan.groups, G);
     G16_LAUNCH_CHECK();
@@ -1456,6 +1491,7 @@ int build_window_tables(const Affine<F>* d_src, uint64_t n, int c, int W, Affine
     template int msm_reduce<typename C::Fq>(const MsmBuffers<typename C::Fq>&, const ScalarSort&, hipStream_t);             \
     template int msm_reduce_batch<typename C::Fq>(const MsmBuffers<typename C::Fq>* const*, const ScalarSort* const*, int, hipStream_t, bool); \
     template int msm_heavy_reduce<typename C::Fq>(const MsmBuffers<typename C::Fq>&, const ScalarSort&, hipStream_t);     \
+    template int msm_heavy_reduce_batch<typename C::Fq>(const MsmBuffers<typename C::Fq>* const*, const ScalarSort* const*, int, hipStream_t); \
     template int msm_reduce<typename C::Fq2>(const MsmBuffers<typename C::Fq2>&, const ScalarSort&, hipStream_t);           \
     template XYZZ<typename C::Fq> fold_windows<typename C::Fq>(const XYZZ<typename C::Fq>*, const MsmPlan&);               \
     template XYZZ<typename C::Fq2> fold_windows<typename C::Fq2>(const XYZZ<typename C::Fq2>*, const MsmPlan&);

@@ -179,14 +179,6 @@ struct Prover {
             if (!on) last_end = pass_end[k];
             return G16_OK;
         };
-        // a G1 MSM's heavy-bucket combine (buckets with many partial sums: the short top window's few hundred) goes underneath the
-        // next pass on the MSM's own stream -- at most a few hundred workgroups -- so that the batched reduction starts at the bucket level
-        auto heavy_early = [&](int k, const MsmBuffers<Fq>& buf, const ScalarSort& ss) -> int {
-            G16_HIP_TRY(hipStreamWaitEvent(ctx->red[k], pass_end[k], 0));
-            G16_TRY((msm_heavy_reduce<Fq>(buf, ss, ctx->red[k])));
-            G16_HIP_TRY(hipEventRecord(ctx->ev_heavy[k], ctx->red[k]));
-            return G16_OK;
-        };
         auto copy_out = [&](int k, const auto& buf, const ScalarSort& ss, hipStream_t sr) -> int {
             G16_HIP_TRY(hipMemcpyAsync(pin + k * SLOT, buf.window_sums, sizeof(*buf.window_sums) * ss.plan.outputs(), hipMemcpyDeviceToHost, sr));
             G16_HIP_TRY(hipEventRecord(ctx->ev_done[k], sr));
@@ -224,9 +216,13 @@ struct Prover {
             return x.B == y.B && x.groups == y.groups && x.Lmax == y.Lmax && x.merged == y.merged && x.affine_levels == 0 && y.affine_levels == 0;
         };
         const bool batch_ok = sort_z.plan.affine_levels == 0 || sort_z.max_sorted == 0;
-        const bool h_in_batch = h_ext != nullptr && batch_ok && plans_match(sort_z.plan, sort_h.plan) && !getenv("G16_PASS_NO_BATCH");
+        // (sharded proof: h waits in the same launch -- the launch then waits ~0.4 ms for h's sort, which only gets going when the G2
+        // pass drains, but a fourth launch with its own tail costs more: 8-way share 10.76 vs 11.03 ms, same box.  G16_PASS_H_IN_BATCH=0 / 1)
+        bool h_in_batch = h_ext != nullptr && batch_ok && plans_match(sort_z.plan, sort_h.plan) && !getenv("G16_PASS_NO_BATCH");
+        if (const char* e = getenv("G16_PASS_H_IN_BATCH")) h_in_batch = h_in_batch && atoi(e) != 0;
         int g1_launches = 0;
         bool last_batch = false, early[4] = {false, false, false, false};
+        int early_ev[4] = {0, 1, 2, 3};   // which ev_heavy[] covers MSM k's first reduction stage
         auto run_batch = [&]() -> int {   // whatever is queued in pj[]
             if (!npj) return G16_OK;
             hipEvent_t b0, b1;
@@ -246,8 +242,22 @@ struct Prover {
             for (int i = 0; i < npj; ++i) { pass_begin[pk_of[i]] = b0; pass_end[pk_of[i]] = b1; }
             // the first stage of an MSM's reduction (heavy-bucket combine, then one sum per bucket) goes underneath the NEXT pass on the
             // MSM's own stream; after the last pass there is nothing to hide under, and the batched reduction runs that stage itself
-            if (!last_batch)
-                for (int i = 0; i < npj; ++i) { G16_TRY(heavy_early(pk_of[i], *pj[i].out, *pj[i].ss)); early[pk_of[i]] = true; }
+            // -- as ONE launch per kernel for the whole batch, on ONE side stream: six launches on three streams shared hardware queues
+            // with the G2 reduction's long chain and the last of them came 1 ms late (kernel trace of round 5)
+            if (!last_batch) {
+                const MsmBuffers<Fq>* eb[4];
+                const ScalarSort* es[4];
+                for (int i = 0; i < npj; ++i) { eb[i] = pj[i].out; es[i] = pj[i].ss; }
+                const int k0 = pk_of[0];
+                G16_HIP_TRY(hipStreamWaitEvent(ctx->red[k0], b1, 0));
+                if (batch_ok) {
+                    G16_TRY((msm_heavy_reduce_batch<Fq>(eb, es, npj, ctx->red[k0])));
+                } else {
+                    for (int i = 0; i < npj; ++i) G16_TRY((msm_heavy_reduce<Fq>(*eb[i], *es[i], ctx->red[k0])));
+                }
+                G16_HIP_TRY(hipEventRecord(ctx->ev_heavy[k0], ctx->red[k0]));
+                for (int i = 0; i < npj; ++i) { early[pk_of[i]] = true; early_ev[pk_of[i]] = k0; }
+            }
             npj = 0;
             return G16_OK;
         };
@@ -295,7 +305,7 @@ struct Prover {
             bool any_early = false;
             for (int q = 0; q < nb; ++q) any_early = any_early || early[jobs[idx[q]].k];
             for (int q = 0; q < nb; ++q) {
-                if (early[jobs[idx[q]].k]) G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_heavy[jobs[idx[q]].k], 0));
+                if (early[jobs[idx[q]].k]) G16_HIP_TRY(hipStreamWaitEvent(s1, ctx->ev_heavy[early_ev[jobs[idx[q]].k]], 0));
                 else if (any_early) G16_TRY((msm_heavy_reduce<Fq>(*bb[q], *sp[q], s1)));   // mixed group: this one's first stage here
             }
             G16_TRY((msm_reduce_batch<Fq>(bb, sp, nb, s1, /*heavy_done=*/any_early)));
