@@ -234,3 +234,41 @@ def test_configs4_2_24_eight_ranks_distributed_map_block_h(g, orc):
     assert not h_gpu[-1].any()
     ex = trapdoor_extras(g, curve, ck, toxic, gens["g1gen"], gens["g2gen"])
     assert (proof.flat() == orc.trapdoor_proof(ck, ex, h_orc, r, s)).all()
+
+
+def test_configs4_2_24_eight_ranks_bucket_space_shards(g, orc):
+    """BASELINE.json configs[4] under the OTHER cut of the MSMs (round 5, g16_pk_load_bucket_shard): 2^24 constraints, BLS12-381,
+    world = 8, every rank on the one visible GPU.  The whole key is resident ONCE as window tables (126 GB -- what a rank of this mode
+    holds) and re-labelled rank by rank (g16_pk_rebind_bucket_shard: the tables do not depend on the rank); h comes from the distributed
+    witness map and is all-gathered (the ranks' blocks back to back, h_query loaded in that order); every rank runs
+    g16_prove_partial_h over ALL points and its eighth of the buckets (b mod 8 == rank); g16_prove_finalize folds the eight records.
+    Must not depend on the cut: h (all 2^24 coefficients against the oracle's) and the proof (against the trapdoor closed form)."""
+    import torch
+    from test_gpu_dist_wm import run_all_ranks
+
+    curve, k, world = "bls12_381", 24, 8
+    ck = orc.syn_circuit(curve, k, 4)
+    toxic = orc.rand_fr(curve, 1924, 5)
+    gens = orc.setup(orc.syn_circuit(curve, 2, 1), 3)[1]
+    r, s = orc.rand_fr(curve, 91, 1)[0], orc.rand_fr(curve, 92, 1)[0]
+    with g.Groth16(curve, 0) as prover:
+        mats = mats_of(g, ck)
+        pk = prover.generate_parameters_with_qap(mats, toxic[0], toxic[1], toxic[2], toxic[3], gens["g1gen"], gens["g2gen"], toxic[4])
+        ranks, h_gpu = run_all_ranks(g, prover, mats, ck.z, world)
+        h_all = torch.cat([d.h_local for d in ranks])   # what all_gather_into_tensor leaves on every rank
+        for d in ranks:
+            d.close()
+        torch.cuda.synchronize()
+        shard = (0, world, "bucket")
+        dpk = prover._pk(pk, ck.num_inputs, shard, dist_h=True)
+        info = dpk.info()
+        assert info["table_fallback"] == 0 and info["window_bits_z"] == 20 and info["device_bytes"] > 100e9, info
+        parts = []
+        for i in range(world):
+            dpk.rebind(i, world)
+            parts.append(prover.prove_partial_h(pk, mats, ck.z, shard, h_all.data_ptr(), h_all.shape[0]))
+        proof = prover.prove_finalize(pk, ck.num_inputs, parts, r, s, shard, dist_h=True)
+    h_orc = orc.witness_map(ck)
+    assert (h_gpu == h_orc).all()
+    ex = trapdoor_extras(g, curve, ck, toxic, gens["g1gen"], gens["g2gen"])
+    assert (proof.flat() == orc.trapdoor_proof(ck, ex, h_orc, r, s)).all()
