@@ -746,16 +746,31 @@ def main():
         # (bucket-space shard: the rank folds 1 / world of the (point, window) entries of ALL points -- SURVEY 8(d): the sharded terms
         # divide by the GPU count)
         bucket_div = world if p.mode == "bucket" else 1
-        alg_bytes = n_pts * (base_bytes + 32) // bucket_div
-        avg_ms = float(np.mean(bucket_g1)) if bucket_g1 else float("nan")
+        # The G1 MSMs that are ready together share ONE launch of the kernel (l, a, b_g1; h too in a sharded proof): a "launch" below is
+        # an actual launch (what rocprofv3 --stats averages over), its algorithmic bytes those of the MSMs it walks.
+        g1_points = (p.ranges["h"][1] - p.ranges["h"][0]) + (p.ranges["l"][1] - p.ranges["l"][0]) + 2 * n_pts   # h, l, a, b_g1 (r != 0)
+        g1_launches = max(1, int(round(last_tm.get("g1_pass_launches", 0))) or len([x for x in last_tm["bucket_ms"][:4] if x > 0]))
+        g1_ms_per_step = float(np.sum(bucket_g1)) / args.steps if bucket_g1 else float("nan")
+        alg_bytes = g1_points * (base_bytes + 32) // bucket_div // g1_launches
+        avg_ms = g1_ms_per_step / g1_launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, committed under profiles/);
         # only valid for the workload they were collected on
-        traffic, ntt_traffic, traffic_cal = None, None, None
+        traffic, ntt_traffic, traffic_cal, traffic_src = None, None, None, None
         try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from tree_hash import kernel_source_sha16
+
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             wl = pt["workload"]
-            if wl["curve"] == args.curve and wl["log2_domain"] == args.log2 and wl["n_gpus"] == world:
+            here, there = kernel_source_sha16(ROOT), pt.get("kernel_source_sha16")
+            if here != there:
+                # counters of another tree say nothing about this one's kernels: not reported (re-collect: tools/gpu_session.sh <tag> pmc)
+                traffic_src = (f"profiles/pmc_traffic.json was collected on kernel sources {there} (commit {pt.get('git_commit', '?')}), this run's "
+                               f"are {here}: traffic withheld")
+            elif wl["curve"] == args.curve and wl["log2_domain"] == args.log2 and wl["n_gpus"] == world:
+                traffic_src = (f"profiles/pmc_traffic.json: rocprofv3 --pmc passes of this workload on THIS tree (kernel sources {here}, commit "
+                               f"{pt.get('git_commit', '?')}); collected in their own run, not measured in this one")
                 traffic = pt["hbm_bytes_per_launch"]
                 ntt_traffic = pt.get("ntt_hbm_bytes_per_step")
                 cal = pt.get("calibration")
@@ -773,12 +788,12 @@ def main():
         if n_windows:
             dg = DiagC()
             p.lib.check(p.lib.c.g16_diag_valu(p.ctx, C.byref(dg)))
-            mads = float(n_pts) * n_windows * dg.mads_per_add_g1 / bucket_div
+            mads = float(g1_points) * n_windows * dg.mads_per_add_g1 / bucket_div / g1_launches
             valu = dict(kind="v_mad_u64_u32 issue (integer VALU)", mads_per_launch=mads, achieved_Tmad_s=mads / (avg_ms * 1e-3) / 1e12,
                         measured_peak_Tmad_s=dg.mad_per_s / 1e12, frac=mads / (avg_ms * 1e-3) / dg.mad_per_s,
                         peak_source="g16_diag_valu: mad_rate_kernel timed in this run", mads_per_mixed_add=dg.mads_per_add_g1,
                         mads_per_field_product=dg.mads_per_product, limbs30=dg.limbs, window_bits=int(last_tm.get("window_bits", 0)),
-                        windows=n_windows, points_folded_per_launch=n_pts * n_windows // bucket_div,
+                        windows=n_windows, points_folded_per_launch=g1_points * n_windows // bucket_div // g1_launches,
                         g2=dict(mads_per_mixed_add=dg.mads_per_add_g2, achieved_Tmad_s=float(n_pts) * n_windows * dg.mads_per_add_g2 / bucket_div /
                                 (float(np.mean(bucket_g2)) * 1e-3) / 1e12 if bucket_g2 and np.mean(bucket_g2) > 0 else None))
         # second object for the transforms (2 * 32 * n algorithmic bytes per NTT, seven per proof), from the
@@ -794,12 +809,15 @@ def main():
                                      "(a b - c) / Z, fused into the first sweep of the seventh transform since round 4 (it used to be a "
                                      "0.18 ms kernel outside this timer); replicated on every rank when sharded")
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                        traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload; not measured in this run)" if traffic else None,
+                        traffic_source=traffic_src,
                         traffic_calibration=traffic_cal,
                         binding_resource="integer VALU (v_mad_u64_u32 issue), not HBM: see valu_bound",
                         valu_bound=valu,
-                        kernel="bucket_accumulate30_kernel (G1 Pippenger bucket pass)", launches_per_step=len(bucket_g1) // args.steps,
+                        kernel="bucket_accumulate30_kernel (G1 Pippenger bucket pass)", launches_per_step=g1_launches,
                         avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg_bytes,
+                        msms_per_step=len(bucket_g1) // args.steps, per_msm_ms=g1_ms_per_step / max(1, len(bucket_g1) // args.steps),
+                        launch_note="the G1 MSMs that are ready together go as ONE launch (one tail instead of one per MSM): avg_launch_ms and "
+                                    "algorithmic_bytes_per_launch are per ACTUAL launch (mean over launches of different size), per_msm_ms per MSM",
                         note="integer-VALU bound in practice (10 Fq products per 128 B); see DESIGN.md",
                         g2_bucket_avg_ms=float(np.mean(bucket_g2)))
         out = {

@@ -3,7 +3,11 @@
 
 usage: make_pmc_traffic.py <pmc_traffic_calibrated.json> <curve> <log2_domain> <source note>  > profiles/pmc_traffic.json"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tree_hash import kernel_source_sha16  # noqa: E402
 
 d = json.load(open(sys.argv[1]))
 curve, log2, note = sys.argv[2], int(sys.argv[3]), sys.argv[4]
@@ -40,5 +44,9 @@ out = {
                 f"coalesced read / write factors; algorithmic 7 * 2 * 32 * n = {7 * 64 * (1 << log2) / 1e9:.2f} GB",
     "calibration_kernels": d["calibration"],
     "source": note,
+    # the tree these counters belong to: bench.py reports them only when the running tree hashes the same (tools/tree_hash.py)
+    "kernel_source_sha16": kernel_source_sha16(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+    "g1_launch_note": "per ACTUAL launch of the G1 kernel, averaged over the launches of the profiled run (since round 5 the MSMs that are "
+                      "ready together share one launch: l + a + b_g1, then h)",
 }
 print(json.dumps(out, indent=1))
