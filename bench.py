@@ -465,7 +465,10 @@ def pick_shard_mode(want, world, k, curve, device, dist):
         rows = 13 if k >= 20 else 32                      # window tables: W rows (c = 20: 13; small keys use small windows, more rows)
         need = int(rows * key_bytes * 1.08) + 3 * key_bytes + (8 << 30)
         free, _total = torch.cuda.mem_get_info(device)
-        mode = "bucket" if need < free else "base"
+        # ... and only while the whole key's tables stay below ~80 GiB: at 2^24 (126 GB) the passes of a bucket-space shard gather from
+        # a table eight times the size of a base-range shard's and lose to address translation what the smaller reductions gain
+        # (36.2 vs 36.4 ms per rank, same box) -- no reason to hold 8x the memory and load 8x as long for a tie
+        mode = "bucket" if need < free and rows * key_bytes <= (80 << 30) else "base"
         why = f"auto: whole-key window tables need ~{need / 2**30:.0f} GiB, {free / 2**30:.0f} GiB free -> {mode}"
     if dist is not None and world > 1:
         flag = torch.tensor([1 if mode == "bucket" else 0], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")

@@ -348,7 +348,10 @@ int g16_deserialize_points(int curve, int g2, int compressed, const uint8_t* in,
                            uint64_t* points_out);
 
 /* ---- host-side arithmetic self-test hooks (CPU; used by the `not gpu` tests) ----
- * The same field / group code the kernels use, compiled for the host.
+ * The same field / group code the kernels use, compiled for the host.  They ship IN the product library on purpose: the CPU tier --
+ * the only tier that runs where the library is built, a container without a GPU -- checks the 30-bit lazy arithmetic, its overflow
+ * and bound proofs, the window-table tasks and the bucket-method model (g16_host_selftest, g16_host_msm_model[_shard]) on exactly the
+ * code objects the kernels are generated from.  None of them is on a proof's path; none touches a GPU.
  * which: 0 Fr, 1 Fq.  op: 0 add, 1 sub, 2 mul, 3 inverse(a), 4 to_canonical(a), 5 from_canonical(a) */
 int g16_host_field_op(int curve, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out);
 /* g2: 0/1.  op: 0 p+q (affine in, affine out), 1 k*p (k canonical 4 limbs), 2 p+q via XYZZ+XYZZ add */
