@@ -47,6 +47,7 @@ out = {
     "source": note,
     # the tree these counters belong to: bench.py reports them only when the running tree hashes the same (tools/tree_hash.py)
     "kernel_source_sha16": kernel_source_sha16(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+    "git_commit": os.environ.get("G16_GIT_COMMIT", "?"),   # the GPU box has no .git: passed in by the caller (tools/r05_evidence.sh)
     "g1_launch_note": "per ACTUAL launch of the G1 kernel, averaged over the launches of the profiled run (since round 5 the MSMs that are "
                       "ready together share one launch: l + a + b_g1, then h)",
 }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 5 evidence set, one box, one gpurun call: every number DESIGN.md / BASELINE.md quote for the round's last tree.
-#   usage: gpurun --timeout 1500 -- 'bash tools/r05_evidence.sh r05_final'      (outputs under gpurun_out/<tag>/, copied to profiles/r05_*)
+#   usage: gpurun --timeout 1500 -- "G16_GIT_COMMIT=$(git rev-parse --short HEAD) bash tools/r05_evidence.sh r05_final"
+#   (outputs under gpurun_out/<tag>/, copied to profiles/r05_*; the commit id travels in the environment: the GPU box has no .git)
 set -u
 TAG=$1; O=gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 NOX="--no-cpu-baseline --no-pipelined --no-projection"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""sha256 (first 16 hex digits) over the kernel sources of the product library -- every *.hip / *.hpp under groth16_amd/csrc plus
-include/g16_mi355x.h, in name order.  profiles/pmc_traffic.json records the hash of the tree its counters were collected on;
+"""sha256 (first 16 hex digits) over the kernel sources of the product library -- every *.hip / *.hpp under groth16_amd/csrc, in
+name order (the public header is not part of it: its comments change without the kernels).  profiles/pmc_traffic.json records the hash of the tree its counters were collected on;
 bench.py recomputes it at run time and reports roofline.traffic only when the two agree (the GPU box has no .git to ask)."""
 import hashlib
 import os
@@ -10,7 +10,6 @@ import sys
 def kernel_source_sha16(root):
     d = os.path.join(root, "groth16_amd", "csrc")
     files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".hpp")))
-    files.append(os.path.join(root, "include", "g16_mi355x.h"))
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())
