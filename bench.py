@@ -613,10 +613,15 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        import datetime
+
+        # explicit collective timeout: a rank that dies in its (untimed, minutes at 2^24) setup must surface as an error on the others,
+        # not as a silent wait for the default half hour
+        tmo = datetime.timedelta(minutes=int(os.environ.get("G16_BENCH_COLLECTIVE_TIMEOUT_MIN", "20")))
         if backend == "nccl":
-            dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+            dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, timeout=tmo)
         else:
-            dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist_mod.init_process_group(backend=backend, rank=rank, world_size=world, timeout=tmo)
             device = torch.device("cpu")  # tensors handed to the collective live on the host for gloo
         dist = dist_mod
         if backend == "nccl":

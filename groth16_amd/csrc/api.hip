@@ -64,6 +64,9 @@ static void diag_counts(g16_diag* out) {
     out->mads_per_add_g2 = 2 * ((fused && fused_g2) ? 6 * two_sweeps + 2 * mul + four_sweeps : 8 * two_sweeps + 2 * mul);
 }
 
+// g16_pk_load on a multi-device context: the retry with base ranges after an automatic bucket-space load ran out of memory
+static thread_local bool g_multi_force_base = false;
+
 extern "C" {
 
 int g16_ctx_create(int curve, int device_id, g16_ctx** out) {
@@ -254,8 +257,50 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
         // no base -- instead of a contiguous range; g16_prove then never replicates the transforms
         const bool dist_h = !(view->flags & G16_PK_DEVICE_PTRS) && view->h.points && dist_wm_admissible(n, hl + 1);
         if (dist_h) h->dist_n = hl + 1;
-        const int rc = for_each_device(n, [&](int i) -> int {
+        // How the five MSMs are cut over the devices.  Base ranges: 1 / n of the window tables per device.  Bucket space
+        // (round 5): the WHOLE tables on every device, device i owns the buckets b mod n == i, and the reductions shrink with n too --
+        // chosen (G16_MULTI_SHARD_MODE=auto, the default) while the whole key's tables stay below 80 GiB and fit in the free memory of
+        // every device with room for the per-proof arena; =base / =bucket force.  A forced bucket-space load that does not fit is an
+        // error (no silent fall-back in that mode); auto falls back to base ranges.
+        bool bucket = false, bucket_forced = false;
+        {
+            const char* me = g_multi_force_base ? "base" : getenv("G16_MULTI_SHARD_MODE");
+            if (me && strcmp(me, "bucket") == 0) bucket = bucket_forced = true;
+            else if (!me || strcmp(me, "auto") == 0) {
+                const double key_bytes = (double)(g1b * 8) * (double)(m * 2 + w + hl) + (double)(g2b * 8) * (double)m;
+                const double rows = m >= ((uint64_t)1 << 20) ? 13.0 : 32.0;
+                const double need = rows * key_bytes * 1.08 + 3.0 * key_bytes + 8.0 * 1073741824.0;
+                bucket = rows * key_bytes <= 80.0 * 1073741824.0 && !(view->flags & G16_PK_DEVICE_PTRS);
+                for (g16_ctx* sub : ctx->subs) {
+                    size_t fr = 0, tot = 0;
+                    if (!bucket) break;
+                    if (hipSetDevice(sub->device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); bucket = false; }
+                    // a device listed k times holds k copies (tests)
+                    size_t copies = 0;
+                    for (g16_ctx* o : ctx->subs) copies += o->device == sub->device ? 1 : 0;
+                    if (need * (double)copies > (double)fr) bucket = false;
+                }
+            }
+            if (bucket && (view->flags & G16_PK_DEVICE_PTRS)) { delete h; return G16_ERR_BAD_ARG; }
+        }
+        h->bucket_mode = bucket;
+        std::vector<uint64_t> hgather;   // bucket space + distributed map: h_query in the order the all-gathered blocks of h arrive in
+        if (bucket && dist_h) {
+            const uint64_t M = (hl + 1) / (uint64_t)n, blk = M / (uint64_t)n;
+            hgather.reserve((size_t)(hl * g1b));
+            for (uint64_t q = 0; q < (uint64_t)n; ++q)
+                for (uint64_t k1 = 0; k1 < (uint64_t)n; ++k1)
+                    for (uint64_t j = 0; j < blk; ++j) {
+                        const uint64_t idx = q * blk + j + M * k1;
+                        if (idx < hl) hgather.insert(hgather.end(), view->h.points + idx * g1b, view->h.points + (idx + 1) * g1b);
+                    }
+        }
+        int rc = for_each_device(n, [&](int i) -> int {
             g16_pk_view v = *view;
+            if (bucket) {
+                if (dist_h) { v.h.points = hgather.data(); v.h.count = hgather.size() / g1b; v.h.start = 0; }
+                return g16_pk_load_bucket_shard(ctx->subs[(size_t)i], &v, i, n, &h->subs[(size_t)i]);
+            }
             const uint64_t a_lo = m * (uint64_t)i / n, a_hi = m * (uint64_t)(i + 1) / n;
             const uint64_t l_lo = std::min(w, a_lo > skip ? a_lo - skip : 0), l_hi = std::min(w, a_hi > skip ? a_hi - skip : 0);
             const uint64_t h_lo = hl * (uint64_t)i / n, h_hi = hl * (uint64_t)(i + 1) / n;
@@ -284,6 +329,15 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
             if (dist_h) { v.h.points = hblock.data(); v.h.count = hblock.size() / g1b; v.h.start = 0; }
             return g16_pk_load(ctx->subs[(size_t)i], &v, &h->subs[(size_t)i]);
         }, serial_loads(ctx));
+        if (rc == G16_ERR_OOM && bucket && !bucket_forced) {
+            // auto guessed wrong (other tenants of the HBM): give the partial loads back and cut by base ranges instead
+            for (g16_pk*& sub : h->subs) { g16_pk_free(sub); sub = nullptr; }
+            delete h;
+            g_multi_force_base = true;
+            const int rc2 = g16_pk_load(ctx, view, out);
+            g_multi_force_base = false;
+            return rc2;
+        }
         if (rc) { g16_pk_free(h); return rc; }
         *out = h;
         return G16_OK;
@@ -377,7 +431,8 @@ int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_input
                 for (int k = 0; k < 3; ++k) {
                     if (hipMalloc((void**)&sl.work[k], M * 32) != hipSuccess || hipMalloc((void**)&sl.recv[k], M * 32) != hipSuccess) return G16_ERR_OOM;
                 }
-                if (hipMalloc((void**)&sl.h_local, M * 32) != hipSuccess || hipMalloc((void**)&sl.z_dev, (num_variables ? num_variables : 1) * 32) != hipSuccess)
+                if (hipMalloc((void**)&sl.h_local, M * 32) != hipSuccess || hipMalloc((void**)&sl.z_dev, (num_variables ? num_variables : 1) * 32) != hipSuccess ||
+                    hipMalloc((void**)&sl.h_full, M * (uint64_t)n * 32) != hipSuccess)
                     return G16_ERR_OOM;
                 return G16_OK;
             }, serial_loads(ctx));
@@ -398,7 +453,7 @@ void g16_circuit_free(g16_circuit* c) {
             (void)hipSetDevice(c->ctx->subs[i]->device);
             g16_dwm_free(sl.dwm);
             for (int k = 0; k < 3; ++k) { (void)hipFree(sl.work[k]); (void)hipFree(sl.recv[k]); }
-            (void)hipFree(sl.h_local); (void)hipFree(sl.z_dev);
+            (void)hipFree(sl.h_local); (void)hipFree(sl.z_dev); (void)hipFree(sl.h_full);
         }
         for (g16_circuit* sub : c->subs) g16_circuit_free(sub);
         delete c;
@@ -525,10 +580,24 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                 for (int st = 0; st < 4; ++st) {
                     step([&]() -> int {
                         G16_TRY(g16_dwm_stage_async(sub, sl.dwm, st, zp, n_assign, sl.work, sl.recv, sl.h_local));
-                        if (st < 3) G16_HIP_TRY(hipEventRecord(ev_stage[(size_t)i], sw));
+                        if (st < 3 || pk->bucket_mode) G16_HIP_TRY(hipEventRecord(ev_stage[(size_t)i], sw));
                         return G16_OK;
                     });
-                    if (st == 3) break;
+                    if (st == 3) {
+                        // bucket-space key: every device folds ALL of h (and 1 / n of the buckets) -- it pulls every device's block
+                        // behind that device's last stage, into the order the key's h_query was loaded in (the all-gather as peer copies)
+                        if (pk->bucket_mode)
+                            step([&]() -> int {
+                                G16_HIP_TRY(hipSetDevice(sub->device));
+                                for (int q = 0; q < n; ++q) {
+                                    G16_HIP_TRY(hipStreamWaitEvent(sw, ev_stage[(size_t)q], 0));
+                                    G16_HIP_TRY(hipMemcpyPeerAsync(sl.h_full + (uint64_t)q * M * 4, sub->device, circuit->dist[(size_t)q].h_local,
+                                                                   ctx->subs[(size_t)q]->device, M * 32, sw));
+                                }
+                                return G16_OK;
+                            });
+                        break;
+                    }
                     step([&]() -> int {   // every device's stage event is recorded: pull
                         G16_HIP_TRY(hipSetDevice(sub->device));
                         for (int q = 0; q < n; ++q) G16_HIP_TRY(hipStreamWaitEvent(sw, ev_stage[(size_t)q], 0));
@@ -552,7 +621,8 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                     // the uploaded assignment is read by the MSM streams too: order them after the upload
                     if (hipStreamWaitEvent(sub->stream, ev_up[(size_t)i], 0) != hipSuccess) out_rc = G16_ERR_HIP;
                     else
-                        out_rc = g16_prove_partial_h(sub, pk->subs[(size_t)i], circuit->subs[(size_t)i], zp, n_assign, 1, sl.h_local, M, skip_b_g1,
+                        out_rc = g16_prove_partial_h(sub, pk->subs[(size_t)i], circuit->subs[(size_t)i], zp, n_assign, 1,
+                                                     pk->bucket_mode ? sl.h_full : sl.h_local, pk->bucket_mode ? M * (uint64_t)n : M, skip_b_g1,
                                                      &parts[(size_t)i]);
                 } else if (my == G16_OK) {
                     out_rc = SIBLING_FAILED;

@@ -170,6 +170,7 @@ struct g16_dwm;
 struct DwmSlot {
     g16_dwm* dwm = nullptr;
     uint64_t *work[3] = {nullptr, nullptr, nullptr}, *recv[3] = {nullptr, nullptr, nullptr}, *h_local = nullptr;   // M Fr each
+    uint64_t* h_full = nullptr;  // domain_size Fr: every device's block of h, back to back (the all-gather of a bucket-space key)
     uint64_t* z_dev = nullptr;   // num_variables Fr: a host assignment is uploaded once per proof and device
 };
 
@@ -237,6 +238,8 @@ struct g16_pk {
     std::vector<g16_pk*> subs;        // multi-device context: shard i of the key on device i (dp == nullptr)
     uint64_t dist_n = 0;              // != 0: the h shards are gathered in the block order of the distributed witness map over a
                                       // domain of dist_n points (h_query holds dist_n - 1 bases, generator.rs:168)
+    bool bucket_mode = false;         // multi-device key cut in BUCKET space: every device holds the whole key's tables (h_query in the
+                                      // order the all-gathered blocks arrive in) and owns the buckets b mod n_dev == device index
     uint64_t id = next_key_id();
 };
 

@@ -146,6 +146,11 @@ int g16_ctx_create(int curve, int device_id, g16_ctx** out);
  * circuit's: h_query holds domain_size - 1 bases, generator.rs:168; anything else is G16_ERR_BAD_LENGTH at g16_prove).  g16_prove_partial is the per-device form and is refused on such a context;
  * g16_prove_finalize and the unit-level entry points run on the first device.  device_ids may repeat.  n_dev == 1 is
  * g16_ctx_create.
+ * How g16_pk_load cuts the key over the devices (round 5; G16_MULTI_SHARD_MODE=auto|base|bucket, default auto): by BASE RANGES as above, or in
+ * BUCKET SPACE (g16_pk_load_bucket_shard on every device: the whole key's window tables per device, device i owns the buckets
+ * b mod n_dev == i, and with the distributed witness map every device pulls ALL blocks of h -- the all-gather as peer copies); auto picks
+ * bucket space while the whole key's tables stay below 80 GiB and fit in every device's free memory, and falls back to base ranges if
+ * such a load then runs out of memory (a FORCED bucket-space load does not fall back: G16_ERR_OOM).  g16_pk_get_info says which.
  * EXPERIMENTAL for n_dev > 1 over distinct devices: every test so far ran with one physical GPU listed several times (the build
  * pool has one-GPU boxes), so peer access, hipMemcpyPeerAsync between devices and the cross-device event waits of g16_prove have
  * not met real hardware; tests/test_gpu_parity.py::test_multi_device_context_distinct_gpus runs wherever >= 2 GPUs are visible.

@@ -386,13 +386,17 @@ def test_sharded_proof_equals_single(env, orc, g):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("mode", ["base", "bucket"])
 @pytest.mark.parametrize("n_dev", [3, 2, 4])
-def test_multi_device_context_single_call(orc, g, curve, n_dev):
+def test_multi_device_context_single_call(orc, g, curve, n_dev, mode, monkeypatch):
     """g16_ctx_create_multi: ONE g16_prove over a context of several devices -- here the one visible GPU
     n_dev times -- shards the key inside the library, runs a host thread per device and folds the partial records; the
     proof equals the oracle's, r = 0 included (prover.rs:98-108), and the per-device form is refused on such a context.
     n_dev = 3 replicates the witness map; a power of two distributes it (four stages per device, the all-to-all as peer
-    copies between the devices' buffers, h_query sharded in block order)."""
+    copies between the devices' buffers, h_query sharded in block order).  mode (G16_MULTI_SHARD_MODE): the key cut by base ranges,
+    or -- round 5 -- in bucket space: every device holds the whole key's tables and owns the buckets b mod n_dev == device index; with
+    the distributed map every device then pulls ALL blocks of h (the all-gather as peer copies)."""
+    monkeypatch.setenv("G16_MULTI_SHARD_MODE", mode)
     ck = orc.syn_circuit(curve, 11, 6)
     pk, _ = orc.setup(ck, 4)
     gm, gp = mats_of(g, ck), pk_of(g, pk)
@@ -402,6 +406,8 @@ def test_multi_device_context_single_call(orc, g, curve, n_dev):
             proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck.num_inputs, ck.num_constraints, ck.z)
             assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
         assert prover.timings()["total_ms"] > 0
+        info = prover.pk_info(gp, ck.num_inputs)
+        assert info["n_devices"] == n_dev and info["bucket_shard_world"] == (n_dev if mode == "bucket" else 1), info
         assert (prover.witness_map_from_matrices(gm, ck.num_inputs, ck.num_constraints, ck.z) == orc.witness_map(ck)).all()
         with pytest.raises(g.G16Error):
             prover.prove_partial(gp, gm, ck.z, (0, 1))

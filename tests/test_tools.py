@@ -26,7 +26,7 @@ def test_pmc_traffic_calibration(tmp_path):
     G1 = "void g16::bucket_accumulate30_kernel<g16::Fp30<g16::Bls12_381FqP>, false>(int)"
     G2 = "void g16::bucket_accumulate30_kernel<g16::Fp2p30<g16::Bls12_381FqP>, false>(int)"
     NTT = "void g16::ntt30_pass_kernel<g16::Bls12_381FrP, true>(int)"
-    QUO = "void g16::quotient_kernel<g16::Fp<g16::Bls12_381FrP> >(int)"
+    QUO = "void g16::bitrev_scale_kernel<g16::Bls12_381FrP>(int)"   # one launch per proof: how make_pmc_traffic.py counts the proofs
     # counters are in KiB; the coalesced-read calibration kernel reports half of its true bytes
     fetch = [("calib_read16(V16 const*, unsigned long, unsigned int*)", "FETCH_SIZE", 1000), ("calib_read32(R32 const*)", "FETCH_SIZE", 500),
              ("calib_gather96(R96 const*)", "FETCH_SIZE", 2000), ("calib_gather192p(R48 const*)", "FETCH_SIZE", 1000),
@@ -64,7 +64,8 @@ def test_pmc_traffic_calibration(tmp_path):
     pt = json.loads(run("tools/make_pmc_traffic.py", str(cj), "bls12_381", "22", "unit test"))
     assert pt["workload"] == {"curve": "bls12_381", "log2_domain": 22, "n_gpus": 1}
     assert pt["hbm_bytes_per_launch"] == g1["hbm_bytes_per_launch"] and pt["calibration"]["fetch"]["factor"] == 1.0
-    assert pt["ntt_hbm_bytes_per_step"] == 2 * ntt["hbm_bytes_per_launch"]        # two launches, one proof (one quotient launch)
+    assert pt["ntt_hbm_bytes_per_step"] == 2 * ntt["hbm_bytes_per_launch"]        # two launches, one proof (one un-permute launch)
+    assert len(pt["kernel_source_sha16"]) == 16   # the tree the counters belong to (tools/tree_hash.py)
 
 
 def test_trace_timeline(tmp_path):
