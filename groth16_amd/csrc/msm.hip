@@ -16,15 +16,23 @@
 //                           slice and LDS atomics hand out the slots: a counting sort of
 //                           (point index | sign) by (window, bucket) -- order inside a bucket is
 //                           irrelevant because group addition commutes
+//      (1, 2, 4 as written serve ad-hoc bases -- g16_msm_g1 / _g2; proving-key MSMs use the merged-window variants below:
+//       class_count / class_partition, bucket_count_merged / bucket_wg_scan / bucket_scatter_merged -- no global atomics, 32 KB
+//       histograms that fit on a compute unit beside the bucket passes)
 //   5. bucket_accumulate30_kernel  THE hot kernel: one lane (G1) / lane pair (G2) per 64-entry SEGMENT of the
 //                           sorted list gathers affine bases (96 B / 192 B each) and folds them with XYZZ
 //                           mixed additions (8M+2S, no inversion; Y3 under one reduction) in 30-bit lazy arithmetic
 //                           (fp30.hpp), the running sum's four coordinates parked in LDS (AccParked, round 4),
-//                           flushing one partial sum per (bucket, segment) it touches
-//   5b. heavy_reduce_kernel cooperative combine of buckets with many partial sums
-//   6. bucket_reduce_kernel / window_reduce_kernel   sum_b (b+1) S_b by chunked running sums; chunk offsets through
-//                           bit-plane sums of the chunk totals (MsmPlan in internal.hpp), not a scalar multiplication
-//   7. host                 recombine the planes per group, then sum_w 2^(cw) R_w  (<= 256 doublings)
+//                           flushing one partial sum per (bucket, segment) it touches.  ONE launch walks up to four MSMs
+//                           (PassBatch, round 5: the G1 MSMs of a proof that are ready together -- one tail instead of four)
+//   5b. heavy_reduce_kernel cooperative combine of the FEW buckets with MANY partial sums (> 16)
+//   5c. bucket_combine_kernel (round 5)  every other bucket's partial sums added up by one lane per BUCKET, so that ...
+//   6. bucket_reduce_kernel / window_reduce_kernel   ... sum_b (b+1) S_b by chunked running sums reads ONE sum per bucket: a chain
+//                           of 2 G dependent additions per lane; chunk offsets through bit-plane sums of the chunk totals
+//                           (MsmPlan in internal.hpp), not a scalar multiplication
+//   7. host                 recombine the planes per group, then sum_w 2^(cw) R_w  (<= 256 doublings); a bucket-space shard
+//                           (MsmPlan::shard_n, round 5: the rank owns the buckets b mod N == rank and indexes them by b / N)
+//                           turns its local sums into its share  N sum_k (k+1) S_k - (N - 1 - rank) sum_k S_k
 //
 // Steps 1-4 depend only on the scalars and are shared by every MSM over the same scalar
 // vector (a_query, b_g1_query, b_g2_query and l_query all use the witness: one sort, four
@@ -34,10 +42,10 @@
 // tables T[j][i] = 2^(cj) P_i (build_window_tables_kernel).  Window j's digit of scalar i then selects T[j][i] and ALL
 // windows share one set of 2^(c-1) buckets: sum_i s_i P_i = sum_b (b+1) sum_{(i,j): |d_ij|-1 = b} +-T[j][i].  The bucket
 // count no longer grows with the number of windows, so c rises from 16 to 20 and the bucket pass folds n*13 instead
-// of n*16 points (BLS12-381 and BN254 scalars); the 2^19 buckets are cut into 16 classes of 2^15 for the LDS histogram
-// (*_merged_kernel below), and the reductions treat a class like a window.  Costs 13x the key's memory (31 GB at 2^22
-// constraints on BLS12-381 -- HBM capacity is what this GPU has to spare) and a one-off table build at load time.
-// Roofline: step 5 reads ~N*W*(sizeof(Affine)+4) bytes (6.8 GB measured at 2^22, G1, merged windows) but spends ~10
+// of n*16 points (BLS12-381 and BN254 scalars); the 2^19 buckets are cut into 64 sort classes of 2^13 for the LDS histogram
+// (*_merged_kernel below) and into 16 groups of 2^15 for the reductions, which treat a group like a window.  Costs 13x the key's
+// memory (31 GB at 2^22 constraints on BLS12-381 -- HBM capacity is what this GPU has to spare) and a one-off table build at load time.
+// Roofline: step 5 reads ~N*W*(sizeof(Affine)+4) bytes (6.9 GB measured per MSM at 2^22, G1, merged windows) but spends ~10
 // field products (3 169 v_mad_u64_u32) per 100 bytes, i.e. it is integer-VALU bound, not HBM bound; the
 // bytes/s it sustains is reported against the 8 TB/s roofline by bench.py regardless.
 #include "internal.hpp"
@@ -131,12 +139,13 @@ static __global__ __launch_bounds__(SORT_THREADS) void bucket_count_kernel(const
 
 // ---------------------------------------------------------------------------------------------
 // 1m/2m/4m. merged-window variants: every (point, window) digit is an entry of ONE bucket set of 2^(c-1) buckets, cut
-// into Q classes of B = 2^blog <= 2^15 buckets (what the LDS histogram holds).  Two levels:
+// into Q sort classes of 2^blog <= 2^13 buckets (what the LDS histogram holds: SORT_CLASS_LOG below).  Two levels:
 //   class_count_kernel / class_partition_kernel   entries -> Q contiguous class regions (block-local LDS cursors on top
 //                           of scanned per-(class, block) counts); an entry is a u16 key (bucket in class | sign << 15)
 //                           and a u32 tag (point | window << 26)
-//   bucket_count_merged_kernel / bucket_scatter_merged_kernel   per class: the same LDS counting sort as above, reading
-//                           the class region instead of a digit plane.   Sorted entry = point | window << 26 | sign << 31.
+//   bucket_count_merged_kernel / bucket_wg_scan_kernel / bucket_scatter_merged_kernel   per class: an LDS counting sort over the
+//                           class region, its histograms exchanged through a [class][workgroup][bucket] matrix instead of global
+//                           atomics.   Sorted entry = point | window << 26 | sign << 31.
 // ---------------------------------------------------------------------------------------------
 static constexpr int CLASS_THREADS = 256;
 static constexpr int MAX_CLASSES = 64;

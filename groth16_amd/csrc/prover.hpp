@@ -148,11 +148,12 @@ struct Prover {
         }
         char* pin = static_cast<char*>(ctx->pinned);
         if (sort_z.plan.outputs() > MSM_MAX_OUTPUTS || sort_h.plan.outputs() > MSM_MAX_OUTPUTS) return G16_ERR_INTERNAL;
-        // Bucket passes back to back on stream 1.  The G2 MSM goes first and its reduction (the longest chain: ~3x a G1 one) runs on
-        // its own stream underneath the G1 passes; the four G1 reductions are NOT started one by one underneath the following
-        // pass -- a reduction is a few hundred waves of dependent additions that hold register slots for milliseconds and slowed
-        // every pass they ran under (8-way shard at 2^22: 1.8-2.1 ms per pass instead of 1.2) -- but run TOGETHER, one launch per
-        // stage for all of them (msm_reduce_batch), after the last pass: 4x the waves per launch, one chain of latency instead of four.
+        // Bucket passes back to back on stream 1: the G2 MSM first -- its reduction (the longest chain: ~3x a G1 one) runs on its own
+        // stream underneath the G1 passes -- then the G1 MSMs that are ready together as ONE launch (l, a, b_g1; round 5), then h, whose
+        // sort has run underneath that launch.  The G1 reductions are NOT started one by one underneath the following pass (a reduction
+        // is a few hundred waves of dependent additions that hold register slots for milliseconds and slowed every pass they ran
+        // under: round 3) but run TOGETHER, one launch per stage for all of them (msm_reduce_batch), after the last pass -- except their
+        // FIRST stage (heavy buckets, then one sum per bucket), which goes underneath the next pass as one launch per kernel.
         const bool short_passes = (uint64_t)pk->a_count * (uint64_t)sort_z.plan.W / (uint64_t)pk->shard_n < 20000000ull;
         // Timestamps: ONE event per boundary between back-to-back passes (the end of pass k is the begin of pass k + 1) instead of a
         // start / stop / done / span-start record around every pass -- each record is a barrier packet the command processor retires
