@@ -663,7 +663,7 @@ def main():
 
     if args.sim_shards:
         assert world == 1
-        mode = "base" if args.shard_mode == "auto" else args.shard_mode
+        mode, _why = pick_shard_mode(args.shard_mode, args.sim_shards, args.log2, args.curve, local_rank, None)   # auto: as N real ranks would
         use_dwm = dist_wm_ok(args.sim_shards)
         p = DeviceProver(args.curve, args.log2, 1, 0, args.sim_shards, local_rank, args.key, dist_wm=use_dwm, mode=mode)
         p.sim = True

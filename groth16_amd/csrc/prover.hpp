@@ -93,9 +93,15 @@ struct Prover {
         // ---- witness map, h = QAP::witness_map_from_matrices (prover.rs:37-42); only the h MSM needs it.  It goes FIRST,
         // alone, on stream 1 (~6 ms at 2^22): underneath the bucket passes their long-lived waves starve it (60+ ms
         // measured) and everything queued behind it piles up at the end of the proof.
+        // G16_MAP_UNDER_PASSES=1 (experiment, round 5): the map on its own stream, the passes waiting only for the witness sort.  A
+        // transform workgroup (38 KB of LDS, one 120-register wave per SIMD) fits beside the G1 kernel's waves -- not beside the G2
+        // kernel's -- so the map would stall under the G2 pass and finish underneath the G1 launch, its ~50 % of idle issue slots filled.
+        const bool overlap_map = !h_ext && getenv("G16_MAP_UNDER_PASSES") != nullptr && atoi(getenv("G16_MAP_UNDER_PASSES")) != 0;
+        hipStream_t sm = overlap_map ? ctx->stream_wm : s1;
         Fr* d_h = nullptr;
         ScalarSort sort_h, sort_z, sort_l;
-        G16_TRY(ctx->t_wm.start(s1));
+        if (overlap_map && !chunked) G16_HIP_TRY(hipStreamWaitEvent(sm, ctx->ev_z, 0));   // behind the staged copy / the caller's position on stream 1
+        G16_TRY(ctx->t_wm.start(sm));
         if (h_ext) {
             // h comes from the distributed map: whatever g16_dwm_stage_async (and the caller's exchanges) enqueued on the
             // witness-map stream must have finished before h is read.  The witness sort (stream 2) does NOT wait for it and runs
@@ -111,11 +117,11 @@ struct Prover {
         } else {
             G16_TRY(ctx->arena.alloc_n(n, &d_h));
             RoctxRange rr("R1CS to QAP witness map");                                                    // prover.rs:36
-            G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, s1, ctx->t_ntt, chunked ? &up : nullptr)));
+            G16_TRY((witness_map_device<C>(ck, d_z, d_h, ctx->arena, sm, ctx->t_ntt, chunked ? &up : nullptr)));
             if (chunked) G16_HIP_TRY(hipEventRecord(ctx->ev_z, ctx->stream_h2d));   // behind the last piece: the whole assignment is in HBM
         }
-        G16_TRY(ctx->t_wm.stop(s1));
-        G16_HIP_TRY(hipEventRecord(ctx->ev_wm, s1));
+        G16_TRY(ctx->t_wm.stop(sm));
+        G16_HIP_TRY(hipEventRecord(ctx->ev_wm, sm));
 
         // ---- stream 2, beside the witness map: assignment = full_assignment[1..] (prover.rs:80-85), ONE digit/sort
         // pass for a, b_g1, b_g2 (and l)
@@ -346,6 +352,7 @@ struct Prover {
         G16_HIP_TRY(hipStreamSynchronize(s1));
         G16_HIP_TRY(hipStreamSynchronize(s2));
         G16_HIP_TRY(hipStreamSynchronize(s3));
+        if (overlap_map) G16_HIP_TRY(hipStreamSynchronize(ctx->stream_wm));
         for (int k = 0; k < 5; ++k) G16_HIP_TRY(hipStreamSynchronize(ctx->red[k]));
         drain.dismiss();
         const double t_end = now_ms();
