@@ -373,6 +373,39 @@ def test_proof_half_identity_key(env, orc, g, scheme, monkeypatch):
     assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
 
 
+@pytest.mark.parametrize("order", ["natural", "scattered", "reversed"])
+def test_host_witness_in_pieces_whatever_columns_the_rows_read(orc, g, order):
+    """A host assignment of 2^17 + 1 variables is uploaded in four pieces and the sparse mat-vec's row blocks follow them, each as soon as
+    the piece holding the LAST column it reads has landed (need_col, computed at g16_circuit_load; witness_map_device / ZUpload).  The
+    product chain reads its columns in row order -- the case the overlap is made for; here the variables are also renumbered at random
+    and in reverse (row block 0 then reads the last piece: no overlap, same proof).  Synthetic-bases key; proof == the oracle's on the
+    same renumbered instance, twice (events and buffers of the first proof must not satisfy the second)."""
+    from helpers import Csr, FlatCircuit
+
+    curve, k = "bn254", 17
+    ck = orc.syn_circuit(curve, k, 29)
+    nv = ck.num_vars
+    perm = np.arange(nv)
+    if order == "scattered":
+        rs = np.random.RandomState(5)
+        perm[2:] = 2 + rs.permutation(nv - 2)          # old witness variable j -> new index perm[j]; the two instance variables stay
+    elif order == "reversed":
+        perm[2:] = np.arange(nv - 1, 1, -1)
+    z = np.zeros_like(ck.z)
+    z[perm] = ck.z
+    abc = [Csr(m.row_ptr, perm[m.col].astype(np.uint32), m.val) for m in ck.abc]
+    ck2 = FlatCircuit(curve, ck.num_inputs, ck.num_constraints, nv, abc, z)
+    pk = orc.synth_pk(ck2, 77)
+    r, s = orc.rand_fr(curve, 51, 1)[0], orc.rand_fr(curve, 52, 1)[0]
+    want, _ = orc.prove(pk, ck2, r, s)
+    with g.Groth16(curve, 0) as prover:
+        gm, gp = mats_of(g, ck2), pk_of(g, pk)
+        for _ in range(2):
+            proof = prover.create_proof_with_reduction_and_matrices(gp, r, s, gm, ck2.num_inputs, ck2.num_constraints, ck2.z)
+            assert (proof.flat() == want).all()
+        assert (prover.witness_map_from_matrices(gm, ck2.num_inputs, ck2.num_constraints, ck2.z) == orc.witness_map(ck)).all()   # h does not depend on the numbering
+
+
 def test_sharded_proof_equals_single(env, orc, g):
     """MSM base sharding: 3 shards on one GPU, partial records combined by prove_finalize"""
     curve, prover = env
