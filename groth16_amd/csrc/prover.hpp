@@ -69,10 +69,12 @@ struct Prover {
         const double t_begin = now_ms();
         DrainOnError drain(ctx);
         // g16_prove_partial_prepare ran for exactly this (key shard, device assignment): its sort is on stream 2 already
-        const bool prepared = ctx->prep.valid && on_device && ctx->prep.pk == pkh && ctx->prep.z == z && ctx->prep.n_assign == n_assign;
+        // (... and for the key AS IT IS NOW: g16_pk_rebind_bucket_shard may have re-labelled it since, and the sort depends on the residue class)
+        const bool prepared = ctx->prep.valid && on_device && ctx->prep.pk == pkh && ctx->prep.z == z && ctx->prep.n_assign == n_assign &&
+                              ctx->prep.sort_z.plan.shard_n == pk->shard_n && ctx->prep.sort_z.plan.shard_r == pk->shard_r;
         const ScalarSort prepared_sort = ctx->prep.sort_z;
         if (prepared) ctx->prep.valid = false;   // consumed: the arena keeps its contents for this call
-        else ctx->reset_arena();
+        else ctx->reset_arena();                 // (drains a prepared sort that is being dropped before its buffers are reused)
         const Fr* d_z = nullptr;
         // a host assignment with the witness map running here: uploaded in pieces BY the map, whose mat-vec follows the pieces
         // (witness_map_device / ZUpload); every other reader of z waits for the last piece.  G16_UPLOAD_CHUNKED=0: one copy (A/B).

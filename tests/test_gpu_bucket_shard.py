@@ -117,11 +117,16 @@ def test_bucket_sharded_proof_distributed_h(g, orc, curve, k, world):
         torch.cuda.synchronize()
         shard = (0, world, "bucket")
         dpk = prover._pk(gp, ck.num_inputs, shard, dist_h=True)
+        z_dev = torch.from_numpy(np.ascontiguousarray(ck.z).view(np.int64)).to("cuda:0")
         for r, s in ((orc.rand_fr(curve, 61, 1)[0], orc.rand_fr(curve, 62, 1)[0]), (np.zeros(4, dtype=np.uint64), orc.rand_fr(curve, 63, 1)[0])):
             parts = []
             for i in range(world):
+                # a witness sort prepared for the key as it was labelled BEFORE (g16_prove_partial_prepare) must not survive the
+                # re-labelling: the sort depends on the residue class
+                prover.prove_partial_prepare(gp, gm, z_dev.data_ptr(), z_dev.shape[0], shard, dist_h=True)
                 dpk.rebind(i, world)
-                parts.append(prover.prove_partial_h(gp, gm, ck.z, shard, h_all.data_ptr(), h_all.shape[0], skip_b_g1=not r.any()))
+                parts.append(prover.prove_partial_h(gp, gm, ck.z, shard, h_all.data_ptr(), h_all.shape[0], skip_b_g1=not r.any(),
+                                                    z_dev_ptr=z_dev.data_ptr()))
             proof = prover.prove_finalize(gp, ck.num_inputs, parts, r, s, shard, dist_h=True)
             assert (proof.flat() == orc.prove(pk, ck, r, s)[0]).all()
         for d in ranks:

@@ -53,7 +53,7 @@ def test_ntt_kernels_keep_their_butterflies_in_registers(kernels):
 
 def test_streaming_kernels_have_no_scratch(kernels):
     for sub in ("spmv3_kernel", "quotient_kernel", "bitrev_scale_kernel", "class_count_kernel", "class_partition_kernel",
-                "bucket_count_merged_kernel", "bucket_scatter_merged_kernel", "digits_kernel", "dwm_column_kernel"):
+                "bucket_count_merged_kernel", "bucket_scatter_merged_kernel", "bucket_wg_scan_kernel", "digits_kernel", "dwm_column_kernel"):
         for name, k in pick(kernels, sub).items():
             assert k["scratch"] == 0, (name, k)
 
@@ -76,3 +76,25 @@ def test_reductions_keep_two_waves_per_simd_and_nothing_in_scratch(kernels):
             for name, k in pick(kernels, sub, field).items():
                 assert k["waves_per_simd"] >= 2, (name, k)
                 assert k["scratch"] == 0, (name, k)
+
+
+def test_counting_sort_fits_on_a_compute_unit_beside_the_g1_bucket_pass(kernels):
+    """Round 5: h's sort cannot start before the witness map ends -- which is when the passes begin -- so its kernels must be able to
+    LIVE BESIDE a pass instead of waiting for a kernel boundary (with 128 KB histograms each of its two big kernels sat out a whole
+    23 ms pass and the h pass then waited 2.3 ms; same box 69.2 -> 65.6 ms per proof).  A compute unit holds eight G1-pass workgroups
+    (one wave each, two per SIMD) = 8 x 13 KB of LDS and 2 x (its registers, in granules of 8) of a SIMD's 512; a sort workgroup is 256
+    lanes = one wave per SIMD and a 32 KB histogram (SORT_CLASS_LOG = 13: dynamic LDS, 4 << 13 bytes).  Both budgets are asserted."""
+    def gran(v):
+        return (v + 7) // 8 * 8
+
+    g1 = pick(kernels, "bucket_accumulate30_kernel", "Fp30<Bls12_381FqP", "false")
+    g1_regs = max(gran(k["vgpr"]) for k in g1.values())
+    g1_lds = max(k["lds"] for k in g1.values())
+    for sub in ("class_count_kernel", "class_partition_kernel", "bucket_count_merged_kernel", "bucket_scatter_merged_kernel",
+                "bucket_wg_scan_kernel", "bucket_slots_kernel", "scan_block_sums_kernel", "scan_block_offsets_kernel", "scan_write_kernel"):
+        for name, k in pick(kernels, sub).items():
+            if sub in ("class_count_kernel", "class_partition_kernel", "bucket_count_merged_kernel", "bucket_scatter_merged_kernel"):
+                assert k["max_flat_wg"] <= 256, (name, k)                                # one wave per SIMD (the others are launched with 256 lanes)
+            assert 2 * g1_regs + gran(k["vgpr"]) <= 512, (name, k, g1_regs)            # registers of a SIMD: two pass waves + one sort wave
+            lds = k["lds"] + ((4 << 13) if "merged" in name else 0)
+            assert 8 * g1_lds + lds <= 160 * 1024, (name, k)                           # LDS of the compute unit
