@@ -650,6 +650,14 @@ template <class P> struct Lazy30<Fp2<P>> {
 //     result replaces the bucket's first partial (the bucket reduction reads only that one for such buckets).
 // ---------------------------------------------------------------------------------------------
 static constexpr int HEAVY_THREADS = 128;
+// Waves per SIMD the one-lane (G1) first-stage reduction kernels are compiled for.  -DG16_FIRST_STAGE_WAVES=4 holds them to 128 registers
+// (92 - 112 B of scratch per lane on BLS12-381) so that one of their waves fits BESIDE two G1-pass waves and the stage runs underneath
+// the next pass instead of waiting for its workgroups to retire -- measured and lost (round 5, same box, profiles/
+// r05_ab_first_stage_128_registers.txt): 65.88 / 65.89 vs 65.57 / 65.52 ms per proof, 8-way share 10.85 / 10.88 vs 10.62 / 10.60 ms.
+// The stage is off the critical path either way; co-resident it takes issue slots from the pass and pays for its spills.
+#ifndef G16_FIRST_STAGE_WAVES
+#define G16_FIRST_STAGE_WAVES 2
+#endif
 static constexpr int HEAVY_BLOCKS = 512;
 
 // The reductions of up to REDUCE_BATCH MSMs run as ONE launch each (blockIdx.y / .z = MSM of the batch): a reduction is a chain of
@@ -669,7 +677,7 @@ struct ReduceBatch {
 
 // (task = one lane, or one lane pair for the lane-pair Fq2: both lanes of a pair run the same control flow)
 template <class F30>
-__global__ __launch_bounds__(HEAVY_THREADS, REDUCE_STREAMED<F30> ? 2 : 1) void heavy_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch) {
+__global__ __launch_bounds__(HEAVY_THREADS, (REDUCE_STREAMED<F30> && F30::LANES_PER_TASK == 1) ? G16_FIRST_STAGE_WAVES : REDUCE_STREAMED<F30> ? 2 : 1) void heavy_reduce_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AccRaw<typename F30::Raw>* sh = reinterpret_cast<AccRaw<typename F30::Raw>*>(smem);
     constexpr uint32_t LPT = F30::LANES_PER_TASK, TASKS = HEAVY_THREADS / LPT;
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(HEAVY_THREADS, REDUCE_STREAMED<F30> ? 2 : 1) void h
 //     reduction runs its chain underneath the G1 passes.
 // ---------------------------------------------------------------------------------------------
 template <class F30>
-__global__ __launch_bounds__(RED_THREADS, 2) void bucket_combine_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t M) {
+__global__ __launch_bounds__(RED_THREADS, F30::LANES_PER_TASK == 1 ? G16_FIRST_STAGE_WAVES : 2) void bucket_combine_kernel(ReduceBatch<AccRaw<typename F30::Raw>, XYZZ<typename F30::Std>> batch, uint32_t M) {
     AccRaw<typename F30::Raw>* __restrict__ partials = batch.partials[blockIdx.y];
     const uint32_t* __restrict__ slot_off = batch.slot_off[blockIdx.y];
     const uint32_t b = (blockIdx.x * RED_THREADS + threadIdx.x) / F30::LANES_PER_TASK;   // lanes of one task are adjacent
