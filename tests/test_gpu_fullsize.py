@@ -272,3 +272,41 @@ def test_configs4_2_24_eight_ranks_bucket_space_shards(g, orc):
     assert (h_gpu == h_orc).all()
     ex = trapdoor_extras(g, curve, ck, toxic, gens["g1gen"], gens["g2gen"])
     assert (proof.flat() == orc.trapdoor_proof(ck, ex, h_orc, r, s)).all()
+
+
+@pytest.mark.parametrize("curve,world", [("bls12_381", 8), ("bn254", 4)])
+def test_headline_size_bucket_space_shards_trapdoor(g, orc, curve, world):
+    """The configuration the projected multi-GPU numbers are quoted on: 2^22 constraints, bucket-space shards, every rank
+    on the one GPU -- distributed witness map, h all-gathered, the resident tables re-labelled rank by rank, the SUM of the ranks' five
+    partial sums equal to the single-GPU proof's (the same key proved whole on the same context) and the proof equal to the trapdoor
+    closed form."""
+    import torch
+    from test_gpu_dist_wm import run_all_ranks
+
+    k = 22
+    ck = orc.syn_circuit(curve, k, 6)
+    toxic = orc.rand_fr(curve, 2924, 5)
+    gens = orc.setup(orc.syn_circuit(curve, 2, 1), 3)[1]
+    r, s = orc.rand_fr(curve, 93, 1)[0], orc.rand_fr(curve, 94, 1)[0]
+    with g.Groth16(curve, 0) as prover:
+        mats = mats_of(g, ck)
+        pk = prover.generate_parameters_with_qap(mats, toxic[0], toxic[1], toxic[2], toxic[3], gens["g1gen"], gens["g2gen"], toxic[4])
+        whole = prover.create_proof_with_reduction_and_matrices(pk, r, s, mats, ck.num_inputs, ck.num_constraints, ck.z)
+        prover.evict_pk(pk)
+        ranks, h_gpu = run_all_ranks(g, prover, mats, ck.z, world)
+        h_all = torch.cat([d.h_local for d in ranks])
+        for d in ranks:
+            d.close()
+        torch.cuda.synchronize()
+        shard = (0, world, "bucket")
+        dpk = prover._pk(pk, ck.num_inputs, shard, dist_h=True)
+        parts = []
+        for i in range(world):
+            dpk.rebind(i, world)
+            parts.append(prover.prove_partial_h(pk, mats, ck.z, shard, h_all.data_ptr(), h_all.shape[0]))
+        proof = prover.prove_finalize(pk, ck.num_inputs, parts, r, s, shard, dist_h=True)
+    assert (proof.flat() == whole.flat()).all()
+    h_orc = orc.witness_map(ck)
+    assert (h_gpu == h_orc).all()
+    ex = trapdoor_extras(g, curve, ck, toxic, gens["g1gen"], gens["g2gen"])
+    assert (proof.flat() == orc.trapdoor_proof(ck, ex, h_orc, r, s)).all()
