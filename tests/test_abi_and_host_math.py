@@ -162,6 +162,45 @@ def test_host_msm_model_bucket_shards_add_up(lb, orc, cp, c_win, world):
     assert lb.c.g16_host_msm_model_shard(cid, 0, ptr64(bases), ptr64(sc), n, -9, 2, 2, ptr64(out)) != 0
 
 
+def test_host_msm_model_bucket_shards_fuzz(lb, orc):
+    """property, over random rank counts, window sizes, sizes and scalar shapes (uniform, small, all equal, mostly zero): the ranks'
+    bucket-space shares -- each from the product's plan / filter / re-index / fold code -- add up to the oracle's MSM.  Deterministic
+    draws (hypothesis with a fixed seed and no example database), BN254 G1 for speed."""
+    from hypothesis import HealthCheck, given, seed, settings
+    from hypothesis import strategies as st
+
+    cp = pm.BN254
+    cid = CURVE_ID[cp.name]
+    bases_all = orc.synth_bases(cp.name, False, 17, 96)
+    pool = orc.rand_fr(cp.name, 4242, 96)
+    small = ints_to_mont(list(range(96)), cp.r, 4)
+
+    @seed(20260926)
+    @settings(max_examples=25, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+    @given(world=st.integers(2, 64), c=st.integers(9, 20), n=st.integers(1, 96), shape=st.sampled_from(["uniform", "small", "equal", "sparse"]),
+           rot=st.integers(0, 95))
+    def prop(world, c, n, shape, rot):
+        bases = np.ascontiguousarray(np.roll(bases_all, rot, axis=0)[:n])
+        if shape == "uniform":
+            sc = np.roll(pool, rot, axis=0)[:n].copy()
+        elif shape == "small":
+            sc = np.roll(small, rot, axis=0)[:n].copy()
+        elif shape == "equal":
+            sc = np.repeat(pool[rot:rot + 1], n, axis=0)
+        else:
+            sc = np.zeros((n, 4), dtype=np.uint64)
+            sc[:: 7] = pool[rot]
+        sc = np.ascontiguousarray(sc)
+        total = None
+        out = np.zeros(bases.shape[1], dtype=np.uint64)
+        for r in range(world):
+            assert lb.c.g16_host_msm_model_shard(cid, 0, ptr64(bases), ptr64(sc), n, -c, r, world, ptr64(out)) == 0
+            total = out.copy() if total is None else orc.group_op(cp.name, False, 0, total, out)
+        assert (total == orc.msm(cp.name, False, bases, sc)).all(), (world, c, n, shape, rot)
+
+    prop()
+
+
 @pytest.mark.parametrize("cp", CURVES, ids=lambda c: c.name)
 def test_host_selftest_fp30(lb, cp):
     """reduced-radix lazy arithmetic of the G1 bucket kernel (fp30.hpp) vs the standard field / group code"""
