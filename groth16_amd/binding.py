@@ -112,6 +112,7 @@ EXPORTS = [
     "g16_host_msm_model", "g16_host_selftest", "g16_strerror", "g16_last_error", "g16_version", "g16_generate_parameters",
     "g16_host_qap_evaluations", "g16_serialized_point_size", "g16_serialize_points", "g16_deserialize_points",
     "g16_pk_load_bucket_shard", "g16_pk_rebind_bucket_shard", "g16_pk_get_info", "g16_msm_bucket_shard", "g16_host_msm_model_shard",
+    "g16_abi_version", "g16_struct_size", "g16_get_timings_sized", "g16_pk_get_info_sized",
 ]
 
 
@@ -190,6 +191,10 @@ class Lib:
         c.g16_prove_finalize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PartialC), C.c_int, u64p, u64p, C.POINTER(ProofC)]
         c.g16_finalize_host.argtypes = [C.c_int, C.POINTER(PkViewC), C.POINTER(PartialC), C.c_int, u64p, u64p, C.POINTER(ProofC)]
         c.g16_get_timings.argtypes = [C.c_void_p, C.POINTER(TimingsC)]
+        c.g16_struct_size.argtypes = [C.c_int]
+        c.g16_struct_size.restype = C.c_uint64
+        c.g16_get_timings_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        c.g16_pk_get_info_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         c.g16_diag_valu.argtypes = [C.c_void_p, C.POINTER(DiagC)]
         c.g16_witness_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, u64p]
         c.g16_msm_g1.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, u64p]

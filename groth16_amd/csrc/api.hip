@@ -271,6 +271,10 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
                 const double rows = m >= ((uint64_t)1 << 20) ? 13.0 : 32.0;
                 const double need = rows * key_bytes * 1.08 + 3.0 * key_bytes + 8.0 * 1073741824.0;
                 bucket = rows * key_bytes <= 80.0 * 1073741824.0 && !(view->flags & G16_PK_DEVICE_PTRS);
+                // a key that may not have merged window tables cannot be cut in bucket space (KeyLoader::pk_load refuses it): plain
+                // bases requested, or nothing to build tables from -- base ranges take any key
+                const char* pc = getenv("G16_MSM_PRECOMP");
+                if ((pc && atoi(pc) == 0) || m <= 1 || hl == 0) bucket = false;
                 for (g16_ctx* sub : ctx->subs) {
                     size_t fr = 0, tot = 0;
                     if (!bucket) break;
@@ -329,8 +333,10 @@ int g16_pk_load(g16_ctx* ctx, const g16_pk_view* view, g16_pk** out) {
             if (dist_h) { v.h.points = hblock.data(); v.h.count = hblock.size() / g1b; v.h.start = 0; }
             return g16_pk_load(ctx->subs[(size_t)i], &v, &h->subs[(size_t)i]);
         }, serial_loads(ctx));
-        if (rc == G16_ERR_OOM && bucket && !bucket_forced) {
-            // auto guessed wrong (other tenants of the HBM): give the partial loads back and cut by base ranges instead
+        if ((rc == G16_ERR_OOM || rc == G16_ERR_BAD_ARG) && bucket && !bucket_forced) {
+            // auto guessed wrong (other tenants of the HBM; a window size the environment forces that admits no merged tables --
+            // the bucket-space loader answers BAD_ARG): give the partial loads back and cut by base ranges instead.  A view that
+            // is bad for its own reasons gets the same code from the retry.
             for (g16_pk*& sub : h->subs) { g16_pk_free(sub); sub = nullptr; }
             delete h;
             g_multi_force_base = true;
@@ -369,6 +375,7 @@ int g16_pk_rebind_bucket_shard(g16_pk* pk, int rank, int world) {
         return G16_OK;
     };
     if (pk->ctx->finprep.key_id == pk->id) pk->ctx->finprep.drop();
+    pk->ctx->drop_prepared_sort(pk->id);   // a prepared sort kept the OLD residue class
     if (pk->curve == G16_BLS12_381) return rebind(static_cast<DevicePk<Bls12_381>*>(pk->dp));
     return rebind(static_cast<DevicePk<Bn254>*>(pk->dp));
 }
@@ -403,6 +410,7 @@ void g16_pk_free(g16_pk* pk) {
     // key hold their own reference to its host side (KeyGlue) and are matched by key id, so they neither dangle nor match a later key
     if (pk->ctx->finprep.key_id == pk->id) pk->ctx->finprep.drop();
     (void)hipSetDevice(pk->ctx->device);
+    pk->ctx->drop_prepared_sort(pk->id);   // its buffers index THIS key's bases (and may still be running on stream 2)
     if (pk->curve == G16_BLS12_381) Impl<Bls12_381>::pk_free(static_cast<DevicePk<Bls12_381>*>(pk->dp));
     else Impl<Bn254>::pk_free(static_cast<DevicePk<Bn254>*>(pk->dp));
     delete pk;
@@ -431,9 +439,8 @@ int g16_circuit_load(g16_ctx* ctx, const g16_csr_view abc[3], uint64_t num_input
                 for (int k = 0; k < 3; ++k) {
                     if (hipMalloc((void**)&sl.work[k], M * 32) != hipSuccess || hipMalloc((void**)&sl.recv[k], M * 32) != hipSuccess) return G16_ERR_OOM;
                 }
-                if (hipMalloc((void**)&sl.h_local, M * 32) != hipSuccess || hipMalloc((void**)&sl.z_dev, (num_variables ? num_variables : 1) * 32) != hipSuccess ||
-                    hipMalloc((void**)&sl.h_full, M * (uint64_t)n * 32) != hipSuccess)
-                    return G16_ERR_OOM;
+                if (hipMalloc((void**)&sl.h_local, M * 32) != hipSuccess || hipMalloc((void**)&sl.z_dev, (num_variables ? num_variables : 1) * 32) != hipSuccess)
+                    return G16_ERR_OOM;   // (h_full: on first use by a bucket-space key, g16_prove)
                 return G16_OK;
             }, serial_loads(ctx));
             if (rc2) { g16_circuit_free(h); return rc2; }
@@ -565,6 +572,11 @@ int g16_prove(g16_ctx* ctx, const g16_pk* pk, const g16_circuit* circuit, const 
                     G16_HIP_TRY(hipEventCreateWithFlags(&ev_stage[(size_t)i], hipEventDisableTiming));
                     G16_HIP_TRY(hipEventCreateWithFlags(&ev_pull[(size_t)i], hipEventDisableTiming));
                     G16_HIP_TRY(hipEventCreateWithFlags(&ev_up[(size_t)i], hipEventDisableTiming));
+                    if (pk->bucket_mode && !sl.h_full && hipMalloc((void**)&sl.h_full, M * (uint64_t)n * 32) != hipSuccess) {
+                        (void)hipGetLastError();
+                        sl.h_full = nullptr;
+                        return G16_ERR_OOM;
+                    }
                     if (!assignment_on_device) {
                         G16_HIP_TRY(hipMemcpyAsync(sl.z_dev, full_assignment, n_assign * 32, hipMemcpyHostToDevice, sw));
                         zp = sl.z_dev;
@@ -892,6 +904,30 @@ const char* g16_strerror(int status) {
 }
 
 const char* g16_last_error(void) { return g_last_error.c_str(); }
-const char* g16_version(void) { return "g16_mi355x 0.1 (gfx950)"; }
+const char* g16_version(void) { return "g16_mi355x 0.2 (gfx950)"; }
+int g16_abi_version(void) { return G16_ABI_VERSION; }
+uint64_t g16_struct_size(int which) {
+    switch (which) {
+        case G16_STRUCT_TIMINGS: return sizeof(g16_timings);
+        case G16_STRUCT_PK_INFO: return sizeof(g16_pk_info);
+        case G16_STRUCT_DIAG: return sizeof(g16_diag);
+        case G16_STRUCT_PROOF: return sizeof(g16_proof);
+        case G16_STRUCT_PARTIAL: return sizeof(g16_partial);
+        case G16_STRUCT_PK_VIEW: return sizeof(g16_pk_view);
+        default: return 0;
+    }
+}
+int g16_get_timings_sized(g16_ctx* ctx, void* out, uint64_t size) {
+    if (!ctx || !out) return G16_ERR_BAD_ARG;
+    memcpy(out, &ctx->tm, (size_t)std::min<uint64_t>(size, sizeof(g16_timings)));
+    return G16_OK;
+}
+int g16_pk_get_info_sized(const g16_pk* pk, void* out, uint64_t size) {
+    if (!out) return G16_ERR_BAD_ARG;
+    g16_pk_info full;
+    G16_TRY(g16_pk_get_info(pk, &full));
+    memcpy(out, &full, (size_t)std::min<uint64_t>(size, sizeof(full)));
+    return G16_OK;
+}
 
 }  // extern "C"

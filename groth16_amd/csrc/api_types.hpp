@@ -105,10 +105,17 @@ struct g16_ctx {
     struct Prepared {
         bool valid = false;
         const g16_pk* pk = nullptr;
+        uint64_t key_id = 0;      // g16_pk::id: a freed key's ADDRESS may be reused by the next load, its id never is
+        uint64_t a_start = 0, a_count = 0;   // the slice of z the sort covers and its window size, as the key had them then
+        int c_z = 0;
         const uint64_t* z = nullptr;
         uint64_t n_assign = 0;
         ScalarSort sort_z;
     } prep;
+    // forget a prepared sort of key `id` (the key is being freed or re-labelled as another rank's shard)
+    void drop_prepared_sort(uint64_t id) {
+        if (prep.valid && prep.key_id == id) { (void)hipStreamSynchronize(stream2); prep.valid = false; }
+    }
     // a prepared sort that is being DROPPED (the next call is not the prove_partial it was made for, or a failed call left it
     // behind) may still be running on stream 2 inside arena buffers: wait for it before the arena is handed out again
     void reset_arena() {
@@ -170,7 +177,8 @@ struct g16_dwm;
 struct DwmSlot {
     g16_dwm* dwm = nullptr;
     uint64_t *work[3] = {nullptr, nullptr, nullptr}, *recv[3] = {nullptr, nullptr, nullptr}, *h_local = nullptr;   // M Fr each
-    uint64_t* h_full = nullptr;  // domain_size Fr: every device's block of h, back to back (the all-gather of a bucket-space key)
+    mutable uint64_t* h_full = nullptr;  // domain_size Fr: every device's block of h, back to back (the all-gather of a bucket-space key);
+                                         // allocated by the first g16_prove with such a key (base-range keys never pay for it)
     uint64_t* z_dev = nullptr;   // num_variables Fr: a host assignment is uploaded once per proof and device
 };
 

@@ -18,6 +18,7 @@
 // 32-bit words (same size as the arkworks form; converted once at g16_pk_load time).
 #pragma once
 #include "field.hpp"
+#include "fips_asm_gen.hpp"
 
 namespace g16 {
 
@@ -213,29 +214,249 @@ struct Fp30 {
         }
         return r;
     }
+#ifndef G16_NO_FIPS
+#define G16_FIPS 1
+#endif
+    // ---- product scanning (round 6): the same sums COLUMN BY COLUMN --------------------------------------------------------
+    // The operand-scanning forms above add the reduction's carry into a column that already holds its limb products: one 64-bit add
+    // per column on top of the shift that produced the carry (26 per product; the compiler also splits column chains and adds
+    // the halves, 33 v_lshl_add_u64 per product in the round-5 ISA).  Column-major, ONE running accumulator takes column c's
+    // products of every sweep and of the reduction, and its carry-out `acc >> 30` is the SEED of column c + 1's multiply-add chain:
+    // the add disappears (v_mad_u64_u32 has a free 64-bit addend), the 2 NL columns of T are never materialised (fewer live
+    // registers), and with the field's REAL modulus limbs in the bound only 5 of 25 columns of a 13-limb product exceed what a
+    // 64-bit accumulator holds (9 "relaxed" columns before).  Such a column continues in a second accumulator seeded with zero; at
+    // the end its low word joins the first (one multiply-add by 1) and its high word, worth 4 units of the next column, joins the
+    // carry (one multiply-add by 4).  Which part of which column starts a new accumulator is decided at compile time by
+    // fips_plan: worst-case bound propagation (operand limbs <= 2^30 - 1, every m_i <= 2^30 - 1, the real p limbs) -- the plan IS
+    // the overflow proof (static_assert on .ok), and the host self-test still runs every form with 128-bit accumulators beside it.
+    // LLVM's reassociation would undo the order (it sorts the late-arriving carry to the END of a column's sum: back to the
+    // separate add), so each accumulation step is pinned with an empty asm on the device.
+    template <int NS>
+    struct FipsPlan {
+        unsigned char seg[2 * NL][NS + 1];   // accumulator index of part k of column c (parts: the NS sweeps, then the reduction)
+        unsigned char nseg[2 * NL];
+        int extra;                           // accumulators beyond the first, summed over the columns (2 multiply-adds each)
+        bool ok;
+    };
+    template <int NS>
+    static constexpr FipsPlan<NS> fips_plan() {
+        typedef unsigned __int128 W;
+        FipsPlan<NS> pl{};
+        const W LIM = (W)1 << 64, M = MASK, W32 = 0xffffffffu;
+        W carry = 0;
+        pl.ok = true;
+        pl.extra = 0;
+        for (int c = 0; c < 2 * NL - 1; ++c) {
+            const int lo = c < NL ? 0 : c - NL + 1, hi = c < NL ? c : NL - 1;
+            W psum = 0;                       // reduction products of this column without m_c p_0 (added after the merge)
+            for (int i = lo; i <= hi; ++i)
+                if (i != c) psum += M * (W)P::p30(c - i);
+            W B[NS + 1] = {};
+            // accumulator 0: the carry-in, m_c p_0 and the low words merged in at the end are reserved up front
+            B[0] = carry + (c < NL ? M * (W)P::p30(0) : (W)0) + (W)NS * W32;
+            int cur = 0;
+            for (int k = 0; k <= NS; ++k) {
+                const W part = k < NS ? (W)(hi - lo + 1) * M * M : psum;
+                if (B[cur] + part >= LIM) {
+                    ++cur;
+                    if (cur > NS || part >= LIM) { pl.ok = false; return pl; }
+                }
+                B[cur] += part;
+                pl.seg[c][k] = (unsigned char)cur;
+            }
+            pl.nseg[c] = (unsigned char)(cur + 1);
+            pl.extra += cur;
+            carry = B[0] >> 30;
+            for (int s = 1; s <= cur; ++s) carry += 4 * (B[s] >> 32);
+        }
+        // (the last carry is the top limb; it fits 32 bits because the VALUE is bounded -- callers' A*B*p/R' <= 0.5 -- not because
+        //  of this all-ones worst case, whose sum would be several R')
+        return pl;
+    }
+    // the generated assembly's plan (fips_asm_gen.hpp) against this one
+    template <int NS>
+    static constexpr bool fips_asm_plan_agrees() {
+        if constexpr (!FipsAsm<P>::available) return true;
+        else {
+            static_assert(NS == 1 || NS == 2 || NS == 4, "assembly exists for one, two and four sweeps");
+            const FipsPlan<NS> pl = fips_plan<NS>();
+            if (!pl.ok || FipsAsm<P>::NL != NL) return false;
+            for (int c = 0; c < 2 * NL - 1; ++c)
+                for (int k = 0; k <= NS; ++k) {
+                    const int want = NS == 1 ? FipsAsm<P>::plan1(c * 2 + k) : NS == 2 ? FipsAsm<P>::plan2(c * 3 + k) : FipsAsm<P>::plan4(c * 5 + k);
+                    if (pl.seg[c][k] != want) return false;
+                }
+            return true;
+        }
+    }
+    // The C++ form's pin: an empty asm the running sum passes through.  It keeps the order, but gfx950's hazard recognizer puts a wait
+    // state (s_nop 0) between an inline asm that defines a register and the next instruction that reads it: ~2 200 per mixed addition,
+    // measured 3.6 % SLOWER than the operand-scanning forms (profiles/r06_ab_fips_pins.txt; an asm that only READS the sum draws no
+    // wait state but lets the scheduler stretch the live ranges: G1 pass 137 -> 248 registers, the lane-pair kernel spills).  The
+    // device therefore runs the chain as hand-scheduled assembly (fips_asm_gen.hpp, generated by gen_fips_asm.py); this form is
+    // what the host runs (plain C++, 64- and 128-bit accumulators) and the device's fallback under -DG16_NO_FIPS_ASM.
+    template <class U>
+    G16_HD static void fips_pin(U& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (sizeof(U) == 8) asm("" : "+v"(v));
+#endif
+    }
+    // sum_k x_k y_k / R' mod p under one reduction; SQR: the single sweep is x_0^2 (symmetric products once, doubled operand)
+    template <class U, int NS, bool SQR>
+    G16_HD static Fp30 fips(const Fp30* const* xs, const Fp30* const* ys) {
+        constexpr FipsPlan<NS> pl = fips_plan<NS>();
+        static_assert(pl.ok, "product-scanning plan: a column does not fit its accumulators");
+        static_assert(!SQR || NS == 1, "the squaring form has one sweep");
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t one = 1u, four = 4u;   // opaque: keeps `acc + lo32 * 1` / `carry + hi32 * 4` ONE v_mad_u64_u32 each
+        asm("" : "+s"(one));
+        asm("" : "+s"(four));
+#else
+        const uint32_t one = 1u, four = 4u;
+#endif
+        uint32_t m[NL], x2[NL];
+        if (SQR) { G16_UNROLL for (int i = 0; i < NL; ++i) x2[i] = xs[0]->l[i] << 1; }
+        Fp30 r;
+        U carry = 0;
+        G16_UNROLL for (int c = 0; c < 2 * NL - 1; ++c) {
+            const int lo = c < NL ? 0 : c - NL + 1, hi = c < NL ? c : NL - 1;
+            U acc[NS + 1];
+            acc[0] = carry;
+            G16_UNROLL for (int s = 1; s <= NS; ++s) acc[s] = 0;
+            G16_UNROLL for (int k = 0; k < NS; ++k) {
+                const int s = pl.seg[c][k];
+                if (SQR) {
+                    G16_UNROLL for (int i = lo; 2 * i < c; ++i) { acc[s] += (U)((uint64_t)x2[i] * xs[0]->l[c - i]); fips_pin(acc[s]); }
+                    if ((c & 1) == 0) { acc[s] += (U)((uint64_t)xs[0]->l[c / 2] * xs[0]->l[c / 2]); fips_pin(acc[s]); }
+                } else {
+                    G16_UNROLL for (int i = lo; i <= hi; ++i) { acc[s] += (U)((uint64_t)xs[k]->l[i] * ys[k]->l[c - i]); fips_pin(acc[s]); }
+                }
+            }
+            {
+                const int s = pl.seg[c][NS];
+                G16_UNROLL for (int i = lo; i <= hi; ++i) {
+                    if (i == c) continue;   // m_c follows below
+                    acc[s] += (U)((uint64_t)m[i] * P::p30(c - i));
+                    fips_pin(acc[s]);
+                }
+            }
+            G16_UNROLL for (int s = 1; s <= NS; ++s)
+                if (s < pl.nseg[c]) { acc[0] += (U)((uint64_t)(uint32_t)acc[s] * one); fips_pin(acc[0]); }
+            if (c < NL) {
+                m[c] = ((uint32_t)acc[0] * P::PINV30) & MASK;
+                acc[0] += (U)((uint64_t)m[c] * P::p30(0));   // low 30 bits vanish
+                fips_pin(acc[0]);
+            } else {
+                r.l[c - NL] = (uint32_t)acc[0] & MASK;
+            }
+            carry = acc[0] >> 30;
+            G16_UNROLL for (int s = 1; s <= NS; ++s)
+                if (s < pl.nseg[c]) {
+                    if constexpr (sizeof(U) == 8) carry += (U)((uint64_t)(uint32_t)(acc[s] >> 32) * four);
+                    else carry += (acc[s] >> 32) * 4;   // the 128-bit shadow run keeps every bit
+                    fips_pin(carry);
+                }
+        }
+        r.l[NL - 1] = (uint32_t)carry;
+        return r;
+    }
     template <class U>
     G16_HD Fp30 mul_cols(const Fp30& b) const {
+#ifdef G16_FIPS
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(G16_NO_FIPS_ASM)
+        if constexpr (sizeof(U) == 8 && FipsAsm<P>::available) {   // the same chain as hand-scheduled assembly (gen_fips_asm.py)
+            static_assert(fips_asm_plan_agrees<1>(), "gen_fips_asm.py and Fp30::fips_plan disagree on the column plan");
+            Fp30 r;
+            FipsAsm<P>::mul(r.l, l, b.l);
+            return r;
+        }
+#endif
+        const Fp30* xs[1] = {this};
+        const Fp30* ys[1] = {&b};
+        return fips<U, 1, false>(xs, ys);
+#else
         U T[2 * NL];
         wide_mul(T, *this, b);
         wide_relax<1>(T);
         return wide_redc(T);
+#endif
     }
     template <class U>
     G16_HD Fp30 sqr_cols() const {
+#ifdef G16_FIPS
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(G16_NO_FIPS_ASM)
+        if constexpr (sizeof(U) == 8 && FipsAsm<P>::available) {
+            static_assert(fips_asm_plan_agrees<1>(), "gen_fips_asm.py and Fp30::fips_plan disagree on the column plan");
+            Fp30 r;
+            FipsAsm<P>::sqr(r.l, l);
+            return r;
+        }
+#endif
+        const Fp30* xs[1] = {this};
+        return fips<U, 1, true>(xs, xs);
+#else
         U T[2 * NL];
         wide_sqr(T, *this);
         wide_relax<1>(T);
         return wide_redc(T);
+#endif
+    }
+    // x1 y1 + x2 y2 under one reduction
+    template <class U>
+    G16_HD static Fp30 mul2_cols(const Fp30& x1, const Fp30& y1, const Fp30& x2, const Fp30& y2) {
+#ifdef G16_FIPS
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(G16_NO_FIPS_ASM)
+        if constexpr (sizeof(U) == 8 && FipsAsm<P>::available) {
+            static_assert(fips_asm_plan_agrees<2>(), "gen_fips_asm.py and Fp30::fips_plan disagree on the column plan");
+            Fp30 r;
+            FipsAsm<P>::mul2(r.l, x1.l, y1.l, x2.l, y2.l);
+            return r;
+        }
+#endif
+        const Fp30* xs[2] = {&x1, &x2};
+        const Fp30* ys[2] = {&y1, &y2};
+        return fips<U, 2, false>(xs, ys);
+#else
+        U T[2 * NL];
+        wide_mul(T, x1, y1);
+        wide_relax<1>(T);
+        wide_mul_add(T, x2, y2);
+        wide_relax<2>(T);
+        return wide_redc(T);
+#endif
+    }
+    // x1 y1 + x2 y2 + x3 y3 + x4 y4 under one reduction
+    template <class U>
+    G16_HD static Fp30 mul4_cols(const Fp30& x1, const Fp30& y1, const Fp30& x2, const Fp30& y2, const Fp30& x3, const Fp30& y3,
+                                 const Fp30& x4, const Fp30& y4) {
+#ifdef G16_FIPS
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(G16_NO_FIPS_ASM)
+        if constexpr (sizeof(U) == 8 && FipsAsm<P>::available) {
+            static_assert(fips_asm_plan_agrees<4>(), "gen_fips_asm.py and Fp30::fips_plan disagree on the column plan");
+            Fp30 r;
+            FipsAsm<P>::mul4(r.l, x1.l, y1.l, x2.l, y2.l, x3.l, y3.l, x4.l, y4.l);
+            return r;
+        }
+#endif
+        const Fp30* xs[4] = {&x1, &x2, &x3, &x4};
+        const Fp30* ys[4] = {&y1, &y2, &y3, &y4};
+        return fips<U, 4, false>(xs, ys);
+#else
+        U T[2 * NL];
+        wide_mul(T, x1, y1);
+        wide_relax<1>(T);
+        wide_mul_add(T, x2, y2);
+        wide_relax<2>(T);
+        wide_mul_add(T, x3, y3);
+        wide_relax<3>(T);
+        wide_mul_add(T, x4, y4);
+        wide_relax<4>(T);
+        return wide_redc(T);
+#endif
     }
     template <class U>
     G16_HD static Fp30 mul_sub_cols(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) {
-        U T[2 * NL];
-        const Fp30 nd = d.neg2();
-        wide_mul(T, a, b);
-        wide_relax<1>(T);
-        wide_mul_add(T, c, nd);
-        wide_relax<2>(T);
-        return wide_redc(T);
+        return mul2_cols<U>(a, b, c, d.neg2());
     }
     G16_HD Fp30 mul_impl(const Fp30& b) const { return mul_cols<uint64_t>(b); }
     G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
@@ -454,19 +675,10 @@ struct Fp2x30 {
     G16_HD Fp2x30 sub(const Fp2x30& o) const { return {c0.template sub<K>(o.c0), c1.template sub<K>(o.c1)}; }
     G16_HD Fp2x30 neg2() const { return {c0.neg2(), c1.neg2()}; }
     G16_HD Fp2x30 mul_impl(const Fp2x30& o) const {
-        uint64_t T[2 * B::NL];
         Fp2x30 r;
         const B nb1 = o.c1.neg16();           // 16p - b1
-        B::wide_mul(T, c0, o.c0);             // a0 b0 + a1 (16p - b1)  ==  a0 b0 - a1 b1  (mod p)
-        B::template wide_relax<1>(T);
-        B::wide_mul_add(T, c1, nb1);
-        B::template wide_relax<2>(T);
-        r.c0 = B::wide_redc(T);
-        B::wide_mul(T, c0, o.c1);             // a0 b1 + a1 b0
-        B::template wide_relax<1>(T);
-        B::wide_mul_add(T, c1, o.c0);
-        B::template wide_relax<2>(T);
-        r.c1 = B::wide_redc(T);
+        r.c0 = B::template mul2_cols<uint64_t>(c0, o.c0, c1, nb1);   // a0 b0 + a1 (16p - b1)  ==  a0 b0 - a1 b1  (mod p)
+        r.c1 = B::template mul2_cols<uint64_t>(c0, o.c1, c1, o.c0);  // a0 b1 + a1 b0
         return r;
     }
     G16_HD Fp2x30 sqr_impl() const {          // (a0 + a1)(a0 - a1), 2 a0 a1
@@ -629,12 +841,7 @@ struct Fp2p30 {
     // x1 y1 + x2 y2 under one reduction
     template <class U>
     G16_HD static B pair_cols(const B& x1, const B& y1, const B& x2, const B& y2) {
-        U T[2 * B::NL];
-        B::wide_mul(T, x1, y1);                       // lane0: a0 b0   lane1: a0 b1
-        B::template wide_relax<1>(T);
-        B::wide_mul_add(T, x2, y2);                   // lane0: + a1(16p-b1)   lane1: + a1 b0
-        B::template wide_relax<2>(T);
-        return B::wide_redc(T);
+        return B::template mul2_cols<U>(x1, y1, x2, y2);   // lane0: a0 b0 + a1(16p-b1)   lane1: a0 b1 + a1 b0
     }
     G16_HD static B pair_sqr(bool hi, const B& m, const B& o) {
         const B x = sel(hi, o.dbl(), m.add(o));                      // lane0: a0+a1      lane1: 2 a0
@@ -650,16 +857,7 @@ struct Fp2p30 {
         const B y2 = sel(hi, ob, ob.neg16());         // lane0: 16p-b1  lane1: b0
         const B z1 = md.neg2();                       // lane0: 2p-d0   lane1: 2p-d1
         const B z2 = sel(hi, od.neg2(), od);          // lane0: d1      lane1: 2p-d0
-        uint64_t T[2 * B::NL];
-        B::wide_mul(T, a0, mb);
-        B::template wide_relax<1>(T);
-        B::wide_mul_add(T, a1, y2);
-        B::template wide_relax<2>(T);
-        B::wide_mul_add(T, c0, z1);
-        B::template wide_relax<3>(T);
-        B::wide_mul_add(T, c1, z2);
-        B::template wide_relax<4>(T);
-        return B::wide_redc(T);
+        return B::template mul4_cols<uint64_t>(a0, mb, a1, y2, c0, z1, c1, z2);
     }
     // Measured in round 2 (profiles/r02_ab_mul_sub.txt, 2^22, same box) inside the register-resident accumulator: the fused form was
     // 4.7 % FASTER for G1 (Fp30::mul_sub) but 5 % SLOWER here (27.9 -> 29.3 ms per G2 pass): eight operand sets + the column array

@@ -1267,6 +1267,18 @@ int msm_bucket_pass(const Affine<F>* d_bases, int64_t shift, uint64_t base_count
     return G16_OK;
 }
 
+// Workgroups of the bucket pass per compute unit.  Since round 6 (product-scanning field products: no 2 NL-column array) the G1 kernel
+// needs ~140 registers and THREE waves per SIMD fit; what is co-resident is then decided by LDS: 13 312 B of parked accumulator per
+// 64-lane workgroup + this pad (unused dynamic LDS).  G16_PASS_WG_PER_CU=n pads so that exactly n workgroups fit (A/B knob).
+template <class F30>
+static unsigned pass_lds_pad() {
+    static const int want = [] { const char* e = getenv("G16_PASS_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    if (want <= 0) return 0;
+    const unsigned own = F30::ACC_PARKED ? 4u * F30::PREFIX_LIMBS * ACC_THREADS * 4u : 16u;
+    const unsigned per = (160u * 1024u / (unsigned)want) & ~255u;
+    return per > own ? per - own : 0;
+}
+
 // the bucket passes of n <= PASS_BATCH MSMs with one bucket layout as ONE launch (PassBatch above)
 template <class F>
 int msm_bucket_pass_batch(const PassJob<F>* jobs, int n, Arena& arena, hipStream_t st, EventTimer* bucket_timer) {
@@ -1292,8 +1304,8 @@ int msm_bucket_pass_batch(const PassJob<F>* jobs, int n, Arena& arena, hipStream
     if (max_segments) {
         const uint64_t lanes = (uint64_t)max_segments * F30::LANES_PER_TASK;
         const dim3 grid((unsigned)((lanes + ACC_THREADS - 1) / ACC_THREADS), (unsigned)n);
-        hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, false>), grid, dim3(ACC_THREADS), 0, st, b, plan.buckets(), 0u, plan.Lmax,
-                           plan.merged ? 1u : 0u);
+        hipLaunchKernelGGL((bucket_accumulate30_kernel<F30, false>), grid, dim3(ACC_THREADS), pass_lds_pad<F30>(), st, b, plan.buckets(), 0u,
+                           plan.Lmax, plan.merged ? 1u : 0u);
         G16_LAUNCH_CHECK();
     }
     if (bucket_timer) G16_TRY(bucket_timer->stop(st));

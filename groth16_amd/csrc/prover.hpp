@@ -41,6 +41,10 @@ struct Prover {
         G16_HIP_TRY(hipEventRecord(ctx->ev_z, ctx->stream2));
         ctx->prep.valid = true;
         ctx->prep.pk = pkh;
+        ctx->prep.key_id = pkh->id;
+        ctx->prep.a_start = pk->a_start;
+        ctx->prep.a_count = pk->a_count;
+        ctx->prep.c_z = pk->c_z;
         ctx->prep.z = z_dev;
         ctx->prep.n_assign = n_assign;
         ctx->prep.sort_z = ss;
@@ -70,8 +74,10 @@ struct Prover {
         DrainOnError drain(ctx);
         // g16_prove_partial_prepare ran for exactly this (key shard, device assignment): its sort is on stream 2 already
         // (... and for the key AS IT IS NOW: g16_pk_rebind_bucket_shard may have re-labelled it since, and the sort depends on the residue class)
-        const bool prepared = ctx->prep.valid && on_device && ctx->prep.pk == pkh && ctx->prep.z == z && ctx->prep.n_assign == n_assign &&
-                              ctx->prep.sort_z.plan.shard_n == pk->shard_n && ctx->prep.sort_z.plan.shard_r == pk->shard_r;
+        const bool prepared = ctx->prep.valid && on_device && ctx->prep.pk == pkh && ctx->prep.key_id == pkh->id && ctx->prep.z == z &&
+                              ctx->prep.n_assign == n_assign && ctx->prep.a_start == pk->a_start && ctx->prep.a_count == pk->a_count &&
+                              ctx->prep.c_z == pk->c_z && ctx->prep.sort_z.plan.shard_n == pk->shard_n &&
+                              ctx->prep.sort_z.plan.shard_r == pk->shard_r;
         const ScalarSort prepared_sort = ctx->prep.sort_z;
         if (prepared) ctx->prep.valid = false;   // consumed: the arena keeps its contents for this call
         else ctx->reset_arena();                 // (drains a prepared sort that is being dropped before its buffers are reused)

@@ -120,7 +120,9 @@ typedef struct {
 /* phase timings of the last g16_prove on this ctx, milliseconds (GPU events + host clock);
  * names follow the reference's timers (prover.rs:36,62,89,99,111,119) */
 typedef struct {
-    double witness_map_ms;
+    double witness_map_ms; /* for a HOST assignment (assignment_on_device == 0) the upload's pieces land UNDER the map's first kernels, whose
+                              row blocks wait for them: the figure then includes the ~2.4 ms (2^22) the 128 MiB take to arrive; with
+                              the assignment resident, or G16_UPLOAD_CHUNKED=0 (one copy ahead of the timer), it is the map alone */
     double msm_h_ms, msm_l_ms, msm_a_ms, msm_b_g1_ms, msm_b_g2_ms;
     double scalar_prep_ms; /* into_bigint + digit extraction + bucket sort (shared by the MSMs) */
     double finish_ms;      /* host glue: scalar muls, final adds, into_affine */
@@ -377,6 +379,18 @@ const char* g16_strerror(int status);
 /* text of the last HIP error seen on this thread ("" if none) */
 const char* g16_last_error(void);
 const char* g16_version(void);
+/* ABI revision of this header: bumped whenever a struct written by the library GROWS (fields are only ever appended).  2 = round 5's
+ * g16_timings.g1_pass_launches and g16_pk_info.  A caller compiled against an older header must not let the library write the
+ * longer struct into its shorter one: it checks g16_abi_version() == G16_ABI_VERSION at start-up, or asks for the library's struct
+ * sizes (g16_struct_size), or uses the *_sized readers below, which copy min(size, library's size) bytes and never more. */
+#define G16_ABI_VERSION 2
+int g16_abi_version(void);
+enum { G16_STRUCT_TIMINGS = 0, G16_STRUCT_PK_INFO = 1, G16_STRUCT_DIAG = 2, G16_STRUCT_PROOF = 3, G16_STRUCT_PARTIAL = 4, G16_STRUCT_PK_VIEW = 5 };
+/* sizeof the library's own idea of a struct of this header; 0 for an unknown `which` */
+uint64_t g16_struct_size(int which);
+/* g16_get_timings / g16_pk_get_info into a caller struct of `size` bytes (its sizeof at ITS compile time) */
+int g16_get_timings_sized(g16_ctx* ctx, void* out, uint64_t size);
+int g16_pk_get_info_sized(const g16_pk* pk, void* out, uint64_t size);
 
 #ifdef __cplusplus
 }

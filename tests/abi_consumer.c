@@ -91,6 +91,16 @@ int main(int argc, char** argv) {
     } else if (rc != G16_ERR_NO_DEVICE) {
         ++failures;
     }
+    /* ABI revision: the library's struct sizes are this header's, and a SHORT caller struct is never overrun (an "old caller":
+     * the first 8 bytes of g16_pk_info asked for, a canary right behind them) */
+    if (g16_abi_version() != G16_ABI_VERSION) ++failures;
+    if (g16_struct_size(G16_STRUCT_TIMINGS) != sizeof(g16_timings) || g16_struct_size(G16_STRUCT_PK_INFO) != sizeof(g16_pk_info) ||
+        g16_struct_size(G16_STRUCT_DIAG) != sizeof(g16_diag) || g16_struct_size(G16_STRUCT_PROOF) != sizeof(g16_proof) ||
+        g16_struct_size(G16_STRUCT_PARTIAL) != sizeof(g16_partial) || g16_struct_size(G16_STRUCT_PK_VIEW) != sizeof(g16_pk_view) ||
+        g16_struct_size(99) != 0)
+        ++failures;
+    if (g16_get_timings_sized(NULL, a, sizeof a) == G16_OK || g16_pk_get_info_sized(NULL, a, 8) == G16_OK) ++failures;
+    printf("\"abi_version\": %d,\n", g16_abi_version());
     rc = g16_ctx_create(7, 0, &ctx); /* no such curve */
     if (rc == G16_OK) ++failures;
     printf("\"failures\": %d\n}\n", failures);

@@ -38,6 +38,7 @@ def test_header_compiles_as_c99_and_the_c_calls_work(consumer):
     assert consumer["field_op_0"] == 1 and consumer["field_op_1"] == 1
     assert consumer["ctx_create"] in (0, 6)   # a context, or G16_ERR_NO_DEVICE on a box without a GPU
     assert consumer["version"]
+    assert consumer["abi_version"] == 2
 
 
 @pytest.mark.parametrize("name", sorted(MIRRORS))
