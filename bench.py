@@ -644,6 +644,15 @@ def main():
         seen = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(seen, mine)
         ranks_seen = [dict(rank=int(x[0]), device=int(x[1]), device_uuid_word=f"{int(x[2]):014x}", pid=int(x[3])) for x in seen]
+        # an N-rank number must come from N GPUs: a mis-pinned launch (LOCAL_RANK ignored, one visible device) fails HERE, on every
+        # rank alike (all of them hold the same list), instead of printing an 8-rank line measured on fewer devices.  The test tier's
+        # all-ranks-on-device-0 runs say so explicitly (G16_BENCH_FORCE_DEVICE0).
+        n_distinct = len({(r_["device"], r_["device_uuid_word"]) for r_ in ranks_seen})
+        if n_distinct < world and not os.environ.get("G16_BENCH_FORCE_DEVICE0"):
+            if rank == 0:
+                print(json.dumps({"error": f"{world} ranks on {n_distinct} distinct device(s): refusing to time a multi-GPU run", "ranks": ranks_seen}))
+            dist.destroy_process_group()
+            sys.exit(3)
 
     gpu = torch.device(f"cuda:{local_rank}")
 
@@ -719,6 +728,44 @@ def main():
         gathered = [torch.empty_like(pt) for _ in range(world)]
         dist.all_gather(gathered, pt)
         assert all(bool((x == gathered[0]).all()) for x in gathered), "ranks disagree on the proof"
+
+    # the collectives of one sharded proof, each timed ALONE after the timed steps (same tensors, same process group, HIP events on the
+    # current stream, max over ranks): the terms a measured N > 1 line can be compared with the one-GPU projection by -- the projection
+    # holds everything but these
+    collective_ms = None
+    if dist is not None and world > 1 and backend == "nccl":
+        collective_ms = {}
+
+        def time_coll(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return round(float(t.item()), 4)
+
+        rec = torch.zeros(C.sizeof(PartialC), dtype=torch.uint8, device=device)
+        rec_out = [torch.empty_like(rec) for _ in range(world)]
+        collective_ms["record_all_gather"] = time_coll(lambda: dist.all_gather(rec_out, rec))
+        if p.dwm is not None:
+            M = int(p.dwm.M)
+            a2a_src = torch.zeros((M, 4), dtype=torch.int64, device=device)
+            a2a_dst = torch.empty_like(a2a_src)
+            one = time_coll(lambda: dist.all_to_all_single(a2a_dst, a2a_src))
+            collective_ms["all_to_all_one_array"] = one
+            collective_ms["all_to_all_per_proof_x7"] = round(7 * one, 4)
+            if p.mode == "bucket":
+                hf = torch.empty((M * world, 4), dtype=torch.int64, device=device)
+                collective_ms["h_all_gather"] = time_coll(lambda: dist.all_gather_into_tensor(hf, a2a_src))
+            del a2a_src, a2a_dst
+        collective_ms["note"] = ("each collective timed alone (5 calls back to back, HIP events, max over ranks); inside a proof they are "
+                                 "enqueued on the witness-map stream beside the witness sort")
 
     # PCIe-inclusive rates (SURVEY.md 8(d) defines the metric with the witness on the host at entry; `value` above is the
     # HBM-resident rate the bench contract asks for): the same proof with full_assignment uploaded inside the call, from
@@ -860,6 +907,8 @@ def main():
             out["collective_backend"] = "rccl (torch.distributed nccl)" if backend == "nccl" else backend
             out["ranks"] = ranks_seen
             out["distinct_devices"] = len({(r_["device"], r_["device_uuid_word"]) for r_ in ranks_seen})
+            if collective_ms is not None:
+                out["collective_ms"] = collective_ms
         if world == 1 and not args.no_projection:
             try:
                 out["projected_scaling"] = projected_scaling(p, ms_per_step, args.steps, dist_wm_ok)

@@ -103,6 +103,8 @@ struct Fp30 {
     }
     // 2p - a, for a <= 2p (used on canonical inputs)
     G16_HD Fp30 neg2() const { return zero().template sub<2>(*this); }
+    // canonical a -> a or 2p - a (a signed digit's +-P): a trait so that the bound-propagating stand-in can return the worse of the two
+    G16_HD static Fp30 cond_neg2(const Fp30& a, bool flip) { return flip ? a.neg2() : a; }
     // 16p - a, for a < 16p
     G16_HD Fp30 neg16() const { return zero().template sub<16>(*this); }
     typedef Fp<P> Std;
@@ -252,8 +254,9 @@ struct Fp30 {
             for (int i = lo; i <= hi; ++i)
                 if (i != c) psum += M * (W)P::p30(c - i);
             W B[NS + 1] = {};
-            // accumulator 0: the carry-in, m_c p_0 and the low words merged in at the end are reserved up front
-            B[0] = carry + (c < NL ? M * (W)P::p30(0) : (W)0) + (W)NS * W32;
+            // accumulator 0: the carry-in, m_c p_0, the low words merged in at the end and (the assembly's fused forms) one 32-bit
+            // difference K p_j - s_j are reserved up front
+            B[0] = carry + (c < NL ? M * (W)P::p30(0) : (W)0) + (W)(NS + 2) * W32;   // + 2: a fused subtraction's K p_j - s_j, slack
             int cur = 0;
             for (int k = 0; k <= NS; ++k) {
                 const W part = k < NS ? (W)(hi - lo + 1) * M * M : psum;
@@ -458,6 +461,63 @@ struct Fp30 {
     G16_HD static Fp30 mul_sub_cols(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) {
         return mul2_cols<U>(a, b, c, d.neg2());
     }
+    // ---- products with the group formulas' lazy subtractions folded in (round 6) --------------------------------------------
+    // a b / R' + K p - s and a^2 / R' + 6 p - (u + 2 v): on the device the difference K p_j - s_j rides in column NL + j of the
+    // product's assembly block (gen_fips_asm.py: one 32-bit subtraction + one multiply-add by 1 per limb; the stand-alone
+    // subtraction costs 13 + 12 * 3 instructions for its carry pass).  Same integer, hence the same normalised limbs, as the
+    // two-step forms the host runs -- preconditions and bounds are those of sub<K> (BoundF checks them through the same names).
+    template <int K>
+    G16_HD Fp30 mul_sub_k(const Fp30& b, const Fp30& s) const {
+        static_assert(K == 2 || K == 4 || K == 8, "fused subtraction: K = 2, 4, 8");
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_FIPS) && !defined(G16_NO_FIPS_ASM) && !defined(G16_NO_FUSED_SUB)
+        if constexpr (FipsAsm<P>::has_sub) {
+            static_assert(fips_asm_plan_agrees<1>(), "gen_fips_asm.py and Fp30::fips_plan disagree on the column plan");
+            Fp30 r;
+            if constexpr (K == 2) FipsAsm<P>::mul_s2(r.l, l, b.l, s.l);
+            else if constexpr (K == 4) FipsAsm<P>::mul_s4(r.l, l, b.l, s.l);
+            else FipsAsm<P>::mul_s8(r.l, l, b.l, s.l);
+            return r;
+        }
+#endif
+        return mul(b).template sub<K>(s);
+    }
+    template <int K>
+    G16_HD static Fp30 mul2_sub_k(const Fp30& x1, const Fp30& y1, const Fp30& x2, const Fp30& y2, const Fp30& s) {
+        static_assert(K == 2 || K == 4 || K == 8, "fused subtraction: K = 2, 4, 8");
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_FIPS) && !defined(G16_NO_FIPS_ASM) && !defined(G16_NO_FUSED_SUB)
+        if constexpr (FipsAsm<P>::has_sub) {
+            static_assert(fips_asm_plan_agrees<2>(), "gen_fips_asm.py and Fp30::fips_plan disagree on the column plan");
+            Fp30 r;
+            if constexpr (K == 2) FipsAsm<P>::mul2_s2(r.l, x1.l, y1.l, x2.l, y2.l, s.l);
+            else if constexpr (K == 4) FipsAsm<P>::mul2_s4(r.l, x1.l, y1.l, x2.l, y2.l, s.l);
+            else FipsAsm<P>::mul2_s8(r.l, x1.l, y1.l, x2.l, y2.l, s.l);
+            return r;
+        }
+#endif
+        return mul2_cols<uint64_t>(x1, y1, x2, y2).template sub<K>(s);
+    }
+    // this^2 + 6 p - (u + 2 v)   (X3 = R^2 - PPP - 2 Q of the XYZZ additions; u, v < ~1.5 p normalised)
+    G16_HD Fp30 sqr_sub_x3(const Fp30& u, const Fp30& v) const {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_FIPS) && !defined(G16_NO_FIPS_ASM) && !defined(G16_NO_FUSED_SUB)
+        if constexpr (FipsAsm<P>::has_sub) {
+            Fp30 r;
+            FipsAsm<P>::sqr_x3(r.l, l, u.l, v.l);
+            return r;
+        }
+#endif
+        return sqr().template sub<6>(u.add_dbl(v));
+    }
+    // this * b + 6 p - (u + 2 v)   (the lane pair's X3: its squaring is a product of prepared operands)
+    G16_HD Fp30 mul_sub_x3(const Fp30& b, const Fp30& u, const Fp30& v) const {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_FIPS) && !defined(G16_NO_FIPS_ASM) && !defined(G16_NO_FUSED_SUB)
+        if constexpr (FipsAsm<P>::has_sub) {
+            Fp30 r;
+            FipsAsm<P>::mul_x3(r.l, l, b.l, u.l, v.l);
+            return r;
+        }
+#endif
+        return mul_impl(b).template sub<6>(u.add_dbl(v));
+    }
     G16_HD Fp30 mul_impl(const Fp30& b) const { return mul_cols<uint64_t>(b); }
     G16_HD_NOINLINE static Fp30 mul_outlined(Fp30 a, Fp30 b) { return a.mul_impl(b); }
     // a*b - c*d with ONE Montgomery reduction (the double-width sums share it): 3 NL^2 multiply-adds instead of 4 NL^2.
@@ -474,6 +534,8 @@ struct Fp30 {
         return mul_sub_cols<uint64_t>(a, b, c, d);
 #endif
     }
+    // a*b + c*d under one reduction (the sign-tracking mixed addition's Y: no operand is negated)
+    G16_HD static Fp30 mul_add_fused(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) { return mul2_cols<uint64_t>(a, b, c, d); }
     // the fused form unconditionally: AccParked (bucket pass) has the registers for it -- its accumulator is not in them
     G16_HD static Fp30 mul_sub_fused(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) {
 #ifdef G16_NO_MUL_SUB_FUSED
@@ -674,6 +736,7 @@ struct Fp2x30 {
     template <int K>
     G16_HD Fp2x30 sub(const Fp2x30& o) const { return {c0.template sub<K>(o.c0), c1.template sub<K>(o.c1)}; }
     G16_HD Fp2x30 neg2() const { return {c0.neg2(), c1.neg2()}; }
+    G16_HD static Fp2x30 cond_neg2(const Fp2x30& a, bool flip) { return flip ? a.neg2() : a; }
     G16_HD Fp2x30 mul_impl(const Fp2x30& o) const {
         Fp2x30 r;
         const B nb1 = o.c1.neg16();           // 16p - b1
@@ -700,6 +763,9 @@ struct Fp2x30 {
         return sqr_outlined(*this);
 #endif
     }
+    template <int K>
+    G16_HD Fp2x30 mul_sub_k(const Fp2x30& o, const Fp2x30& s) const { return mul(o).template sub<K>(s); }
+    G16_HD Fp2x30 sqr_sub_x3(const Fp2x30& u, const Fp2x30& v) const { return sqr().template sub<KM + K2M>(u.add_dbl(v)); }
     G16_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
     G16_HD bool is_zero_exact() const { return c0.is_zero_exact() && c1.is_zero_exact(); }
     G16_HD Std to_std() const { return {c0.to_std(), c1.to_std()}; }
@@ -707,6 +773,7 @@ struct Fp2x30 {
     static constexpr int KM = 2, K2M = 4, KX = 8, KY = 4;
     G16_HD static Fp2x30 mul_sub(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return a.mul(b).template sub<KM>(c.mul(d)); }
     G16_HD static Fp2x30 mul_sub_fused(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return mul_sub(a, b, c, d); }
+    G16_HD static Fp2x30 mul_add_fused(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return a.mul(b).add(c.mul(d)); }
     G16_HD Fp2x30 settle() const { return *this; }
     G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     typedef Fp2x30 Raw;
@@ -747,6 +814,7 @@ struct Fp2k30 {
     template <int K>
     G16_HD Fp2k30 sub(const Fp2k30& o) const { return {c0.template sub<K>(o.c0), c1.template sub<K>(o.c1)}; }
     G16_HD Fp2k30 neg2() const { return {c0.neg2(), c1.neg2()}; }
+    G16_HD static Fp2k30 cond_neg2(const Fp2k30& a, bool flip) { return flip ? a.neg2() : a; }
     G16_HD static B bmul(const B& a, const B& b) {
 #ifdef G16_FP2K_INLINE
         return a.mul_impl(b);
@@ -763,6 +831,9 @@ struct Fp2k30 {
     G16_HD Fp2k30 sqr() const {                                 // both components < 2p
         return {bmul(c0.add(c1), c0.template sub<16>(c1)), bmul(c0.dbl(), c1)};
     }
+    template <int K>
+    G16_HD Fp2k30 mul_sub_k(const Fp2k30& o, const Fp2k30& s) const { return mul(o).template sub<K>(s); }
+    G16_HD Fp2k30 sqr_sub_x3(const Fp2k30& u, const Fp2k30& v) const { return sqr().template sub<16>(u.add_dbl(v)); }
     G16_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
     G16_HD bool is_zero_exact() const { return c0.is_zero_exact() && c1.is_zero_exact(); }
     G16_HD Std to_std() const { return {c0.to_std(), c1.to_std()}; }
@@ -771,6 +842,7 @@ struct Fp2k30 {
     static constexpr int KM = 8, K2M = 16, KX = 2, KY = 2;
     G16_HD static Fp2k30 mul_sub(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return a.mul(b).template sub<KM>(c.mul(d)); }
     G16_HD static Fp2k30 mul_sub_fused(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return mul_sub(a, b, c, d); }
+    G16_HD static Fp2k30 mul_add_fused(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return a.mul(b).add(c.mul(d)); }
     G16_HD Fp2k30 settle() const { return {c0.weak_reduce32(), c1.weak_reduce32()}; }
     G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     typedef Fp2x30<P> Raw;
@@ -816,7 +888,9 @@ struct Fp2p30 {
     // partner lane's value (lane ^ 1)
     G16_HD static uint32_t swap32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+        // bound_ctrl = true: every lane of the quad is a valid source, so no "old" value exists -- with update_dpp(0, ...) the compiler
+        // initialised the destination (v_mov_b32 dst, zero) before every v_mov_b32_dpp: 156 of them per lane-pair mixed addition
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 #else
         return v;
 #endif
@@ -831,33 +905,72 @@ struct Fp2p30 {
         G16_UNROLL for (int i = 0; i < B::NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
         return r;
     }
-    // ---- pure per-lane kernels (host-testable): `mine`/`other` are this lane's / the partner's components
-    G16_HD static B pair_mul(bool hi, const B& ma, const B& oa, const B& mb, const B& ob) {
-        const B x1 = sel(hi, oa, ma);                 // lane0: a0      lane1: a0
-        const B x2 = sel(hi, ma, oa);                 // lane0: a1      lane1: a1
+    // the EVEN / ODD lane's value in both lanes of the pair (component 0 / component 1 of an Fq2 value): one DPP move per limb.  Round 6:
+    // the first operand of a product is needed as (a0, a1) in BOTH lanes -- two broadcasts instead of a swap and two selects per limb
+    G16_HD static uint32_t bcast32(uint32_t v, bool odd) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return odd ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xF5 /* quad_perm [1,1,3,3] */, 0xF, 0xF, true)
+                   : (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xA0 /* quad_perm [0,0,2,2] */, 0xF, 0xF, true);
+#else
+        return v;
+#endif
+    }
+    G16_HD static B comp0(const B& x) { B r; G16_UNROLL for (int i = 0; i < B::NL; ++i) r.l[i] = bcast32(x.l[i], false); return r; }
+    G16_HD static B comp1(const B& x) { B r; G16_UNROLL for (int i = 0; i < B::NL; ++i) r.l[i] = bcast32(x.l[i], true); return r; }
+    // ---- pure per-lane kernels (host-testable).  `_c` forms: a0, a1 = BOTH components of the first operand (the same in both lanes),
+    // mb / ob = this lane's / the partner's component of the second.  The (mine, other) forms below select (a0, a1) and forward.
+    G16_HD static B pair_mul_c(bool hi, const B& a0, const B& a1, const B& mb, const B& ob) {
         const B y2 = sel(hi, ob, ob.neg16());         // lane0: 16p-b1  lane1: b0
-        return pair_cols<uint64_t>(x1, mb, x2, y2);
+        return pair_cols<uint64_t>(a0, mb, a1, y2);   // lane0: a0 b0 + a1 (16p-b1)   lane1: a0 b1 + a1 b0
+    }
+    G16_HD static B pair_mul(bool hi, const B& ma, const B& oa, const B& mb, const B& ob) {
+        return pair_mul_c(hi, sel(hi, oa, ma), sel(hi, ma, oa), mb, ob);
     }
     // x1 y1 + x2 y2 under one reduction
     template <class U>
     G16_HD static B pair_cols(const B& x1, const B& y1, const B& x2, const B& y2) {
-        return B::template mul2_cols<U>(x1, y1, x2, y2);   // lane0: a0 b0 + a1(16p-b1)   lane1: a0 b1 + a1 b0
+        return B::template mul2_cols<U>(x1, y1, x2, y2);
     }
-    G16_HD static B pair_sqr(bool hi, const B& m, const B& o) {
-        const B x = sel(hi, o.dbl(), m.add(o));                      // lane0: a0+a1      lane1: 2 a0
-        const B y = sel(hi, m, m.template sub<16>(o));               // lane0: a0-a1+16p  lane1: a1
+    // (a0 + a1)(a0 - a1), 2 a0 a1:   lane0: x = a0 + a1, y = a0 - a1 + 16p      lane1: x = 2 a0, y = a1
+    G16_HD static void pair_sqr_operands(bool hi, const B& a0, const B& a1, B& x, B& y) {
+        x = a0.add(sel(hi, a0, a1));                  // ONE addition serves both lanes (was: a doubling, an addition and a select)
+        y = sel(hi, a1, a0.template sub<16>(a1));
+    }
+    G16_HD static B pair_sqr_c(bool hi, const B& a0, const B& a1) {
+        B x, y;
+        pair_sqr_operands(hi, a0, a1, x, y);
         return x.mul_impl(y);
     }
+    G16_HD static B pair_sqr(bool hi, const B& m, const B& o) { return pair_sqr_c(hi, sel(hi, o, m), sel(hi, m, o)); }
     // this lane's component of a*b - c*d (d's components < 2p): four limb-product sweeps, ONE reduction
     //     lane 0:  a0 b0 + a1 (16p - b1) + c0 (2p - d0) + c1 d1        lane 1:  a0 b1 + a1 b0 + c0 (2p - d1) + c1 (2p - d0)
-    G16_HD static B pair_mul_sub(bool hi, const B& ma, const B& oa, const B& mb, const B& ob, const B& mc, const B& oc, const B& md,
-                                 const B& od) {
-        const B a0 = sel(hi, oa, ma), a1 = sel(hi, ma, oa);
-        const B c0 = sel(hi, oc, mc), c1 = sel(hi, mc, oc);
+    G16_HD static B pair_mul_sub_c(bool hi, const B& a0, const B& a1, const B& mb, const B& ob, const B& c0, const B& c1, const B& md,
+                                   const B& od) {
         const B y2 = sel(hi, ob, ob.neg16());         // lane0: 16p-b1  lane1: b0
         const B z1 = md.neg2();                       // lane0: 2p-d0   lane1: 2p-d1
         const B z2 = sel(hi, od.neg2(), od);          // lane0: d1      lane1: 2p-d0
+#ifdef G16_PAIR_Y3_SPLIT
+        // two two-sweep products and a lazy sum (one reduction more; measured no faster at three waves per SIMD: the passes are bound by
+        // their vector-instruction count, profiles/r06_ab_g2_three_waves.txt); output < 2 (1 + T / (R' p)) p
+        return B::template mul2_cols<uint64_t>(a0, mb, a1, y2).add(B::template mul2_cols<uint64_t>(c0, z1, c1, z2));
+#else
         return B::template mul4_cols<uint64_t>(a0, mb, a1, y2, c0, z1, c1, z2);
+#endif
+    }
+    G16_HD static B pair_mul_sub(bool hi, const B& ma, const B& oa, const B& mb, const B& ob, const B& mc, const B& oc, const B& md,
+                                 const B& od) {
+        return pair_mul_sub_c(hi, sel(hi, oa, ma), sel(hi, ma, oa), mb, ob, sel(hi, oc, mc), sel(hi, mc, oc), md, od);
+    }
+    // this lane's component of a*b + c*d (d's components < 2p): ONE negated operand instead of the difference's three
+    //     lane 0:  a0 b0 + a1 (16p - b1) + c0 d0 + c1 (2p - d1)        lane 1:  a0 b1 + a1 b0 + c0 d1 + c1 d0
+    G16_HD static B pair_mul_add_c(bool hi, const B& a0, const B& a1, const B& mb, const B& ob, const B& c0, const B& c1, const B& md,
+                                   const B& od) {
+        const B y2 = sel(hi, ob, ob.neg16());         // lane0: 16p-b1  lane1: b0
+        const B z2 = sel(hi, od, od.neg2());          // lane0: 2p-d1   lane1: d0
+        return B::template mul4_cols<uint64_t>(a0, mb, a1, y2, c0, md, c1, z2);
+    }
+    G16_HD static Fp2p30 mul_add_fused(const Fp2p30& a, const Fp2p30& b, const Fp2p30& c, const Fp2p30& d) {
+        return {pair_mul_add_c(lane_hi(), comp0(a.c), comp1(a.c), b.c, swap(b.c), comp0(c.c), comp1(c.c), d.c, swap(d.c))};
     }
     // Measured in round 2 (profiles/r02_ab_mul_sub.txt, 2^22, same box) inside the register-resident accumulator: the fused form was
     // 4.7 % FASTER for G1 (Fp30::mul_sub) but 5 % SLOWER here (27.9 -> 29.3 ms per G2 pass): eight operand sets + the column array
@@ -865,7 +978,7 @@ struct Fp2p30 {
     // pass, whose accumulator sits in LDS since round 4, uses mul_sub_fused below.
     G16_HD static Fp2p30 mul_sub(const Fp2p30& a, const Fp2p30& b, const Fp2p30& c, const Fp2p30& d) {
 #ifdef G16_PAIR_MUL_SUB
-        return {pair_mul_sub(lane_hi(), a.c, swap(a.c), b.c, swap(b.c), c.c, swap(c.c), d.c, swap(d.c))};
+        return {pair_mul_sub_c(lane_hi(), comp0(a.c), comp1(a.c), b.c, swap(b.c), comp0(c.c), comp1(c.c), d.c, swap(d.c))};
 #else
         return a.mul(b).template sub<2>(c.mul(d));
 #endif
@@ -876,7 +989,7 @@ struct Fp2p30 {
 #ifdef G16_NO_MUL_SUB_FUSED
         return a.mul(b).template sub<2>(c.mul(d));
 #else
-        return {pair_mul_sub(lane_hi(), a.c, swap(a.c), b.c, swap(b.c), c.c, swap(c.c), d.c, swap(d.c))};
+        return {pair_mul_sub_c(lane_hi(), comp0(a.c), comp1(a.c), b.c, swap(b.c), comp0(c.c), comp1(c.c), d.c, swap(d.c))};
 #endif
     }
     G16_HD static Fp2p30 zero() { return {B::zero()}; }
@@ -887,8 +1000,23 @@ struct Fp2p30 {
     template <int K>
     G16_HD Fp2p30 sub(const Fp2p30& o) const { return {c.template sub<K>(o.c)}; }
     G16_HD Fp2p30 neg2() const { return {c.neg2()}; }
-    G16_HD Fp2p30 mul(const Fp2p30& o) const { return {pair_mul(lane_hi(), c, swap(c), o.c, swap(o.c))}; }
-    G16_HD Fp2p30 sqr() const { return {pair_sqr(lane_hi(), c, swap(c))}; }
+    G16_HD static Fp2p30 cond_neg2(const Fp2p30& a, bool flip) { return flip ? a.neg2() : a; }
+    G16_HD Fp2p30 mul(const Fp2p30& o) const { return {pair_mul_c(lane_hi(), comp0(c), comp1(c), o.c, swap(o.c))}; }
+    // the products with a lazy subtraction folded in (Fp30::mul2_sub_k / mul_sub_x3): each lane subtracts from ITS component
+    template <int K>
+    G16_HD static B pair_mul_sub_k(bool hi, const B& a0, const B& a1, const B& mb, const B& ob, const B& sub) {
+        const B y2 = sel(hi, ob, ob.neg16());
+        return B::template mul2_sub_k<K>(a0, mb, a1, y2, sub);
+    }
+    template <int K>
+    G16_HD Fp2p30 mul_sub_k(const Fp2p30& o, const Fp2p30& s) const { return {pair_mul_sub_k<K>(lane_hi(), comp0(c), comp1(c), o.c, swap(o.c), s.c)}; }
+    G16_HD static B pair_sqr_sub_x3(bool hi, const B& a0, const B& a1, const B& u, const B& v) {
+        B x, y;
+        pair_sqr_operands(hi, a0, a1, x, y);
+        return x.mul_sub_x3(y, u, v);
+    }
+    G16_HD Fp2p30 sqr_sub_x3(const Fp2p30& u, const Fp2p30& v) const { return {pair_sqr_sub_x3(lane_hi(), comp0(c), comp1(c), u.c, v.c)}; }
+    G16_HD Fp2p30 sqr() const { return {pair_sqr_c(lane_hi(), comp0(c), comp1(c))}; }
     G16_HD static bool both(bool v) { return v && (swap32(v ? 1u : 0u) != 0u); }
     G16_HD bool maybe_zero() const { return both(c.maybe_zero()); }
     G16_HD bool is_zero_exact() const { return both(c.is_zero_exact()); }
@@ -1150,17 +1278,30 @@ struct AccParked {
     enum { CX = 0, CY = 1, CZZ = 2, CZZZ = 3 };
     Store s;
     bool inf;
+    // Sign tracking (round 6).  madd-2008-s ends with Y3 = R (Q - X3) - y PPP: a DIFFERENCE of products, i.e. one operand negated
+    // with its own carry pass (PPP -> 2p - PPP, three such operands for the lane pair).  The SUM R (X3 - Q) + y PPP = -Y3 needs
+    // none -- and (X3, -Y3, ZZ, ZZZ) is simply the NEGATED result.  So the parked sum is allowed to be -A (`neg`): the next point
+    // then enters with its sign flipped too (free: the signed digit already selects +-P, the two flips are one exclusive-or),
+    // -A + (-P) = -(A + P), the formula's own negation makes it +(A + P), and `neg` toggles with every hot-path addition.
+    // The cold branches (doubling, first point) keep the sign they find; gather() hands out +A (y -> 4p - y when neg: once per flush).
+    bool neg = false;
 
-    G16_HD void set_identity() { inf = true; }
-    G16_HD Acc30<F> gather() const {
+    G16_HD void set_identity() { inf = true; neg = false; }
+    G16_HD Acc30<F> gather_as_parked() const {   // the coordinates as they lie (the represented point is -A when neg)
         Acc30<F> a;
         a.inf = inf;
         if (inf) { a.x = a.y = a.zz = a.zzz = F::zero(); return a; }
         a.x = s.ld(CX); a.y = s.ld(CY); a.zz = s.ld(CZZ); a.zzz = s.ld(CZZZ);
         return a;
     }
+    G16_HD Acc30<F> gather() const {
+        Acc30<F> a = gather_as_parked();
+        if (!inf && neg) a.y = F::zero().template sub<4>(a.y);   // y < 3.5p (the doubling's two-product Y3 is the largest) -> 4p - y < 4p
+        return a;
+    }
     G16_HD void scatter(const Acc30<F>& a) {
         inf = a.inf;
+        neg = false;
         if (inf) return;
         s.st(CX, a.x); s.st(CY, a.y); s.st(CZZ, a.zz); s.st(CZZZ, a.zzz);
     }
@@ -1178,17 +1319,23 @@ struct AccParked {
         s.st(CY, F::mul_sub(M, S.template sub<F::KX>(X3), py, s.ld(CZZZ)).settle());   // (cold path: two plain products, fewer registers)
         inf = false;
     }
-    // madd-2008-s: this += (px, py), affine, px, py < 2p, not the identity
-    G16_HD void add_affine(const F& px, const F& py) {
+    // madd-2008-s: this += (px, +-py), affine canonical px, py, not the identity; `minus`: subtract the point (the signed digit's sign)
+    G16_HD void add_affine(const F& px, const F& py) { add_affine_signed(px, py, false); }
+    G16_HD void add_affine_signed(const F& px, const F& py_in, bool minus) {
+#ifdef G16_NO_SIGN_TRACK
+        const bool flip = minus;
+#else
+        const bool flip = minus != (neg && !inf);   // the point takes the parked sum's sign as well
+#endif
+        const F py = F::cond_neg2(py_in, flip);
         if (inf) {
             s.st(CX, px); s.st(CY, py); s.st(CZZ, F::one()); s.st(CZZZ, F::one());
             inf = false;
+            neg = false;
             return;
         }
-        const F U2 = px.mul(s.ld(CZZ));
-        const F S2 = py.mul(s.ld(CZZZ));
-        const F Pd = U2.template sub<F::KX>(s.ld(CX));
-        const F R = S2.template sub<F::KY>(s.ld(CY));
+        const F Pd = px.template mul_sub_k<F::KX>(s.ld(CZZ), s.ld(CX));    // U2 - x
+        const F R = py.template mul_sub_k<F::KY>(s.ld(CZZZ), s.ld(CY));    // S2 - y
         if (Pd.maybe_zero()) {
             if (Pd.is_zero_exact()) {   // P == +-Q: doubling (the sum is 2 (px, py), whatever the accumulator's scale) or cancellation
                 if (R.is_zero_exact()) set_double(px, py);
@@ -1206,10 +1353,16 @@ struct AccParked {
 #ifdef G16_NO_FUSED_X3
         const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
 #else
-        const F X3 = R.sqr().template sub<F::KM + F::K2M>(PPP.add_dbl(Q)).settle();
+        static_assert(F::KM + F::K2M == 6, "sqr_sub_x3 subtracts from 6 p");
+        const F X3 = R.sqr_sub_x3(PPP, Q).settle();   // R^2 + 6 p - (PPP + 2 Q), the subtraction inside the squaring's high columns
 #endif
         s.st(CX, X3);
+#ifdef G16_NO_SIGN_TRACK
         s.st(CY, F::mul_sub_fused(R, Q.template sub<F::KX>(X3), s.ld(CY), PPP).settle());
+#else
+        s.st(CY, F::mul_add_fused(R, X3.template sub<F::KM>(Q), s.ld(CY), PPP).settle());   // = -Y3: the parked sum changes sign
+        neg = !neg;
+#endif
     }
 };
 
@@ -1251,8 +1404,8 @@ G16_HD void acc_add_streamed(D& d, bool& d_inf, const S& s, bool s_inf) {
     }
     const F U1 = d.ld(CX).mul(s.ld(CZZ));
     const F S1 = d.ld(CY).mul(s.ld(CZZZ));
-    const F Pd = s.ld(CX).mul(d.ld(CZZ)).template sub<F::KM>(U1);
-    const F R = s.ld(CY).mul(d.ld(CZZZ)).template sub<F::KM>(S1);
+    const F Pd = s.ld(CX).template mul_sub_k<F::KM>(d.ld(CZZ), U1);
+    const F R = s.ld(CY).template mul_sub_k<F::KM>(d.ld(CZZZ), S1);
     if (Pd.maybe_zero()) {
         if (Pd.is_zero_exact()) {
             if (R.is_zero_exact()) acc_dbl_streamed<F>(d, d_inf);   // the same point: double it
@@ -1265,7 +1418,8 @@ G16_HD void acc_add_streamed(D& d, bool& d_inf, const S& s, bool s_inf) {
     const F PPP = Pd.mul(PP);
     d.st(CZZZ, d.ld(CZZZ).mul(s.ld(CZZZ)).mul(PPP));
     const F Q = U1.mul(PP);
-    const F X3 = R.sqr().template sub<F::KM + F::K2M>(PPP.add_dbl(Q)).settle();
+    static_assert(F::KM + F::K2M == 6, "sqr_sub_x3 subtracts from 6 p");
+    const F X3 = R.sqr_sub_x3(PPP, Q).settle();
     d.st(CX, X3);
     d.st(CY, F::mul_sub(R, Q.template sub<F::KX>(X3), S1, PPP).settle());
 }

@@ -49,7 +49,7 @@ def plan(pl, NL, NS):
         hi = c if c < NL else NL - 1
         psum = sum(MASK * pl[c - i] for i in range(lo, hi + 1) if i != c)
         B = [0] * (NS + 1)
-        B[0] = carry + (MASK * pl[0] if c < NL else 0) + NS * W32
+        B[0] = carry + (MASK * pl[0] if c < NL else 0) + (NS + 2) * W32   # + 2: a fused subtraction's K p_j - s_j (and slack)
         cur = 0
         row = []
         for k in range(NS + 1):
@@ -83,8 +83,15 @@ SGPR0 = 36   # first of the NL + 1 physical SGPRs that hold p and -p^-1 when the
              # all the compiler takes -- past ~128 operands it does not terminate)
 
 
-def product(pl, NL, NS, sqr, pinv_val=None, const_sgpr=False):
-    """returns (asm lines, number of operands layout info).  Operand numbering: r[NL] | (sqr: t[NL]) | x_k, y_k ... | p[NL] | pinv"""
+TMP = "v12"   # scratch register of the fused subtraction (physical, clobbered)
+
+
+def product(pl, NL, NS, sqr, pinv_val=None, const_sgpr=False, sub=0):
+    """returns (asm lines, ...).  Operand numbering: r[NL] | (sqr: t[NL]) | x_k, y_k ... | (sub: s[NL] | sub == 2: u[NL], v[NL]) | p[NL] | pinv | (sub: kp[NL])
+    sub = 1: r = product + K p - s (s normalised, K p in the redundant form whose limbs cover any normalised limb);
+    sub = 2: r = product + 6 p - (u + 2 v) (the X3 of the mixed addition; K p with limbs >= 3 (2^30 - 1)).
+    The difference K p_j - s_j (>= 0, < 2^32) joins column NL + j before its limb is taken: one 32-bit subtraction and one
+    multiply-add by 1 per limb instead of the subtraction's own carry-propagating pass (13 + 12 * 3 instructions)."""
     seg, nseg = plan(pl, NL, NS)
     n = 0
     r = ["%%%d" % (n + i) for i in range(NL)]
@@ -102,6 +109,10 @@ def product(pl, NL, NS, sqr, pinv_val=None, const_sgpr=False):
         else:
             ys.append(["%%%d" % (n + i) for i in range(NL)])
             n += NL
+    sub_ops = []
+    for _ in range(sub):
+        sub_ops.append(["%%%d" % (n + i) for i in range(NL)])
+        n += NL
     b = Block()
     if const_sgpr:
         p = ["s%d" % (SGPR0 + i) for i in range(NL)]
@@ -114,6 +125,17 @@ def product(pl, NL, NS, sqr, pinv_val=None, const_sgpr=False):
         n += NL
         pinv = "%%%d" % n
         n += 1
+    kp = None
+    if sub:
+        kp = ["%%%d" % (n + i) for i in range(NL)]
+        n += NL
+
+    def sub_term(j):   # TMP = K p_j - subtrahend_j
+        if sub == 1:
+            b.emit("v_sub_u32 %s, %s, %s" % (TMP, kp[j], sub_ops[0][j]))
+        else:
+            b.emit("v_lshl_add_u32 %s, %s, 1, %s" % (TMP, sub_ops[1][j], sub_ops[0][j]))
+            b.emit("v_sub_u32 %s, %s, %s" % (TMP, kp[j], TMP))
     if sqr:
         for i in range(NL - 1):
             b.emit("v_lshlrev_b32 %s, 1, %s" % (t[i], xs[0][i]))
@@ -150,9 +172,15 @@ def product(pl, NL, NS, sqr, pinv_val=None, const_sgpr=False):
             b.mad(0, r[c], p[0])
             b.emit("v_lshrrev_b64 %s, 30, %s" % (ACC[0], ACC[0]))
         elif c < 2 * NL - 2:
+            if sub:
+                sub_term(c - NL)
+                b.mad(0, TMP, "1")
             b.emit("v_and_b32 %s, 0x3fffffff, %s" % (r[c - NL], ACC_LO[0]))
             b.emit("v_lshrrev_b64 %s, 30, %s" % (ACC[0], ACC[0]))
         else:
+            if sub:
+                sub_term(c - NL)
+                b.mad(0, TMP, "1")
             b.emit("v_and_b32 %s, 0x3fffffff, %s" % (r[c - NL], ACC_LO[0]))
             if nseg[c] > 1:
                 b.emit("v_lshrrev_b64 %s, 30, %s" % (ACC[0], ACC[0]))
@@ -162,6 +190,9 @@ def product(pl, NL, NS, sqr, pinv_val=None, const_sgpr=False):
             b.emit("v_mad_u64_u32 %s, vcc, %s, 4, %s" % (ACC[0], ACC_HI[s], ACC[0]))
         if c == 2 * NL - 2 and nseg[c] > 1:
             b.emit("v_mov_b32 %s, %s" % (r[NL - 1], ACC_LO[0]))
+    if sub:   # the top limb takes its difference with a plain 32-bit add (no carry leaves it)
+        sub_term(NL - 1)
+        b.emit("v_add_u32 %s, %s, %s" % (r[NL - 1], r[NL - 1], TMP))
     return b.lines, seg, nseg, max(nseg)
 
 
@@ -169,14 +200,25 @@ def limbs30(p, nl):
     return [(p >> (30 * i)) & MASK for i in range(nl)]
 
 
-def emit_fn(out, name, pl, NL, NS, sqr, pinv):
+def redundant(p, NL, k, floor_mult):
+    """k p with every limb but the top >= floor_mult * (2^30 - 1) (and < 2^32): limb-wise K p_j - s_j never borrows for s_j up to that"""
+    l = [(k * p >> (30 * i)) & MASK for i in range(NL - 1)] + [k * p >> (30 * (NL - 1))]
+    r = [l[0] + floor_mult * (1 << 30)] + [x + floor_mult * (1 << 30) - floor_mult for x in l[1:-1]] + [l[-1] - floor_mult]
+    assert sum(x << (30 * i) for i, x in enumerate(r)) == k * p and all(0 <= x < (1 << 32) for x in r)
+    assert all(x >= floor_mult * MASK for x in r[:-1])
+    return r
+
+
+def emit_fn(out, name, pl, NL, NS, sqr, pinv, sub=0, kp=None):
     const_sgpr = NS > 2
-    lines, seg, nseg, maxseg = product(pl, NL, NS, sqr, pinv, const_sgpr)
+    lines, seg, nseg, maxseg = product(pl, NL, NS, sqr, pinv, const_sgpr, sub)
     args = ["uint32_t* __restrict__ r"]
     for k in range(NS):
         args.append("const uint32_t* x%d" % k)
         if not sqr:
             args.append("const uint32_t* y%d" % k)
+    for i in range(sub):
+        args.append("const uint32_t* s%d" % i)
     out.append("    static __device__ __forceinline__ void %s(%s) {" % (name, ", ".join(args)))
     if sqr:
         out.append("        uint32_t t[%d];" % NL)
@@ -191,12 +233,18 @@ def emit_fn(out, name, pl, NL, NS, sqr, pinv):
         ins += ['"v"(x%d[%d])' % (k, i) for i in range(NL)]
         if not sqr:
             ins += ['"v"(y%d[%d])' % (k, i) for i in range(NL)]
+    for i in range(sub):
+        ins += ['"v"(s%d[%d])' % (i, j) for j in range(NL)]
     clob = ['"vcc"'] + ['"v%d"' % i for i in range(2, 2 + 2 * maxseg)]
+    if sub:
+        clob.append('"%s"' % TMP)
     if const_sgpr:
         clob += ['"s%d"' % (SGPR0 + i) for i in range(NL + 1)]
     else:
         ins += ['"s"(0x%08xu)' % v for v in pl]
         ins.append('"s"(0x%08xu)' % pinv)
+    if sub:
+        ins += ['"s"(0x%08xu)' % v for v in kp]
     out.append("            : %s" % ", ".join(outs))
     out.append("            : %s" % ", ".join(ins))
     out.append("            : %s);" % ", ".join(clob))
@@ -212,7 +260,7 @@ def main():
     out.append('#include "params_gen.hpp"')
     out.append("namespace g16 {")
     out.append("// forms: mul = x0 y0, sqr = x0^2, mul2 = x0 y0 + x1 y1, mul4 = x0 y0 + ... + x3 y3 (one reduction each); operands are arrays of NL normalised 30-bit limbs")
-    out.append("template <class P> struct FipsAsm { static constexpr bool available = false; };")
+    out.append("template <class P> struct FipsAsm { static constexpr bool available = false; static constexpr bool has_sub = false; };")
     stats = []
     for cname, c in CURVES.items():
         for fname, p in (("Fq", c["q"]), ("Fr", c["r"])):
@@ -223,12 +271,25 @@ def main():
             out.append("template <> struct FipsAsm<%s> {" % sname)
             out.append("    static constexpr bool available = true;")
             out.append("    static constexpr int NL = %d;" % NL)
+            out.append("    static constexpr bool has_sub = %s;   // the forms with a fused subtraction (base fields only)" % ("true" if fname == "Fq" else "false"))
             plans = {}
             out.append("#if defined(__HIP_DEVICE_COMPILE__)")
             for name, NS, sqr in (("mul", 1, False), ("sqr", 1, True), ("mul2", 2, False), ("mul4", 4, False)):
                 seg, nseg, n_ins, n_mad = emit_fn(out, name, pl, NL, NS, sqr, pinv)
                 plans[NS] = (seg, nseg)
                 stats.append((sname, name, n_ins, n_mad))
+            if fname == "Fq":
+                # products with the group formulas' subtractions riding in the high columns: K = 2, 4, 8 (the lazy-bound classes of
+                # Acc30 / AccParked: KM, KY, KX) and the X3 form R^2 + 6 p - (PPP + 2 Q)
+                for K in (2, 4, 8):
+                    kpl = redundant(p, NL, K, 1)
+                    for base, NS, sqr in (("mul", 1, False), ("mul2", 2, False)):
+                        _, _, n_ins, n_mad = emit_fn(out, "%s_s%d" % (base, K), pl, NL, NS, sqr, pinv, 1, kpl)
+                        stats.append((sname, "%s_s%d" % (base, K), n_ins, n_mad))
+                kpw = redundant(p, NL, 6, 3)
+                for base, NS, sqr in (("mul", 1, False), ("sqr", 1, True)):
+                    _, _, n_ins, n_mad = emit_fn(out, "%s_x3" % base, pl, NL, NS, sqr, pinv, 2, kpw)
+                    stats.append((sname, "%s_x3" % base, n_ins, n_mad))
             out.append("#endif")
             for NS, (seg, nseg) in sorted(plans.items()):
                 flat = ", ".join(str(v) for row in seg for v in row)

@@ -61,6 +61,7 @@ struct BoundF {
     BoundF add_dbl(const BoundF& o) const { return {b + 2.0 * o.b}; }
     template <int K> BoundF sub(const BoundF& o) const { check(o.b <= K - 1e-3, "sub<K>: subtrahend not below K p"); return {b + K}; }
     BoundF neg2() const { check(b <= 2.0 - 1e-3 || b == 1.0, "neg2: operand not below 2p"); return {2.0}; }
+    static BoundF cond_neg2(const BoundF& a, bool) { check(a.b <= 1.0, "cond_neg2: operand not canonical"); return {2.0}; }   // the worse of a and 2p - a
     static BoundF product(double A, double B, double T) {
         BoundCtx& c = ctx();
         check(A < c.ratio && B < c.ratio, "product operand does not fit NL limbs");
@@ -71,14 +72,29 @@ struct BoundF {
     }
     BoundF mul(const BoundF& o) const { return ctx().pair ? product(b, o.b > 16.0 ? o.b : 16.0, b * o.b + b * 16.0) : product(b, o.b, b * o.b); }
     BoundF sqr() const { return ctx().pair ? product(2.0 * b, b + 16.0, 2.0 * b * (b + 16.0)) : product(b, b, b * b); }
+    template <int K> BoundF mul_sub_k(const BoundF& o, const BoundF& s) const { return mul(o).template sub<K>(s); }
+    BoundF sqr_sub_x3(const BoundF& u, const BoundF& v) const { return sqr().template sub<6>(u.add_dbl(v)); }
     static BoundF mul_sub(const BoundF& a, const BoundF& bb, const BoundF& c, const BoundF& d) { return a.mul(bb).template sub<2>(c.mul(d)); }
     // the fused a b - c d (one reduction over all sweeps): d enters as 2p - d (< 2p needed); one lane: a b + c (2p - d); lane pair:
     // a0 b0 + a1 (16p - b1) + c0 (2p - d0) + c1 d1  resp.  a0 b1 + a1 b0 + c0 (2p - d1) + c1 (2p - d0)
     static BoundF mul_sub_fused(const BoundF& a, const BoundF& bb, const BoundF& c, const BoundF& d) {
         check(d.b <= 2.0 - 1e-3, "mul_sub_fused: d not below 2p");
         const double A = a.b > c.b ? a.b : c.b;
+#ifdef G16_PAIR_Y3_SPLIT
+        if (ctx().pair) {   // two two-sweep products, summed lazily (fp30.hpp pair_mul_sub)
+            const double Bb = bb.b > 16.0 ? bb.b : 16.0;
+            return {product(a.b, Bb, a.b * bb.b + a.b * Bb).b + product(c.b, 2.0, 4.0 * c.b).b};
+        }
+#endif
         if (ctx().pair) return product(A, bb.b > 16.0 ? bb.b : 16.0, a.b * bb.b + a.b * (bb.b > 16.0 ? bb.b : 16.0) + 4.0 * c.b);
         return product(A, bb.b > 2.0 ? bb.b : 2.0, a.b * bb.b + 2.0 * c.b);
+    }
+    // a b + c d under one reduction (d < 2p); lane pair: a0 b0 + a1 (16p - b1) + c0 d0 + c1 (2p - d1)  resp.  a0 b1 + a1 b0 + c0 d1 + c1 d0
+    static BoundF mul_add_fused(const BoundF& a, const BoundF& bb, const BoundF& c, const BoundF& d) {
+        check(d.b <= 2.0 - 1e-3, "mul_add_fused: d not below 2p");
+        const double A = a.b > c.b ? a.b : c.b;
+        if (ctx().pair) return product(A, bb.b > 16.0 ? bb.b : 16.0, a.b * bb.b + a.b * (bb.b > 16.0 ? bb.b : 16.0) + c.b * d.b + 2.0 * c.b);
+        return product(A, bb.b > d.b ? bb.b : d.b, a.b * bb.b + c.b * d.b);
     }
     BoundF settle() const { return *this; }
     bool maybe_zero() const { check(b < 16.0, "zero test on a value not below 16p"); return false; }
@@ -508,10 +524,11 @@ struct SelfTest {
             AccParked<B, ParkedArrayStore<B>> pk;
             pk.set_identity();
             for (int it = 0; it < 200; ++it) {
-                pk.add_affine(B{1.0}, B{2.0});
-                const A g = pk.gather();
+                pk.add_affine_signed(B{1.0}, B{1.0}, (it & 2) != 0);   // canonical y in; cond_neg2 propagates 2p whatever the signs
+                const A g = pk.gather_as_parked();
                 const double v[4] = {g.x.b, g.y.b, g.zz.b, g.zzz.b};
                 for (int k = 0; k < 4; ++k) if (v[k] > mx[k]) mx[k] = v[k];
+                (void)pk.gather();   // the flush's 4p - y: its precondition (y < 4p) is checked here
             }
             AccParked<B, ParkedArrayStore<B>> pd;
             pd.set_identity();
@@ -521,7 +538,9 @@ struct SelfTest {
         // the invariants fp30.hpp documents for the accumulator
         if (!(mx[0] < 7.5 && mx[1] < 3.5 && mx[2] < 1.8 && mx[3] < 1.8)) { *report = "accumulator bounds above the documented ones"; return 2; }
         // full additions, doublings, mixed doubling on accumulators at those bounds (reduction kernels, heavy combine, P + P branch)
-        A a1; a1.x = B{mx[0]}; a1.y = B{mx[1]}; a1.zz = B{mx[2]}; a1.zzz = B{mx[3]}; a1.inf = false;
+        // (a partial sum leaves the pass with y or 4p - y: the reductions' operands are taken at max(y bound, 4p))
+        const double y_out = mx[1] > 4.0 ? mx[1] : 4.0;
+        A a1; a1.x = B{mx[0]}; a1.y = B{y_out}; a1.zz = B{mx[2]}; a1.zzz = B{mx[3]}; a1.inf = false;
         A a2 = a1;
         for (int it = 0; it < 50; ++it) { a1.add(a2); a2 = a1; a2.dbl(); }
         A a3 = A::identity();
@@ -529,7 +548,7 @@ struct SelfTest {
         if (c.fail) { *report = c.fail; return 3; }
         {   // the reductions' streamed addition / doubling on operands at those bounds, iterated like the chain above
             ParkedArrayStore<B> ds, ss;
-            ds.v[0] = B{mx[0]}; ds.v[1] = B{mx[1]}; ds.v[2] = B{mx[2]}; ds.v[3] = B{mx[3]};
+            ds.v[0] = B{mx[0]}; ds.v[1] = B{y_out}; ds.v[2] = B{mx[2]}; ds.v[3] = B{mx[3]};
             ss = ds;
             bool dinf = false;
             for (int it = 0; it < 50; ++it) {

@@ -592,8 +592,12 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         };
         if constexpr (F30::ACC_PREFETCH) advance();
         if (ok) {
-            if (v >> 31) py = py.neg2();
-            acc.add_affine(px, py);
+            if constexpr (F30::ACC_PARKED) {
+                acc.add_affine_signed(px, py, (v >> 31) != 0);   // the digit's sign and the parked sum's sign are one flip (AccParked)
+            } else {
+                if (v >> 31) py = py.neg2();
+                acc.add_affine(px, py);
+            }
         }
         if constexpr (!F30::ACC_PREFETCH) advance();
     }

@@ -51,7 +51,7 @@ def _worker(rank, world, port, curve, q, mode="base"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         orc = oracle()
-        orc.set_threads(2)
+        orc.set_threads(2 if world <= 2 else 1)
         lb = g.lib()
         ck = orc.syn_circuit(curve, 6, 3)
         pk, _ = orc.setup(ck, 8)  # deterministic: both ranks build the same valid CRS
@@ -109,10 +109,7 @@ def _worker(rank, world, port, curve, q, mode="base"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["base", "bucket"])
-@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
-def test_two_rank_sharded_proof_gloo(curve, mode):
-    world = 2
+def _run_world(world, curve, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -123,14 +120,28 @@ def test_two_rank_sharded_proof_gloo(curve, mode):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(r[0] for r in res) == [0, 1]
+    assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] for r in res), res
     rg = {r[0]: r[2] for r in res}
     for key in ("a", "l", "h"):
-        if mode == "bucket":   # every rank holds every base
-            assert rg[0][key] == rg[1][key] and rg[0][key][0] == 0
-        else:                  # the shards tile every base array exactly once
-            assert rg[0][key][0] == 0 and rg[0][key][1] == rg[1][key][0]
+        for k in range(1, world):
+            if mode == "bucket":   # every rank holds every base
+                assert rg[0][key] == rg[k][key] and rg[0][key][0] == 0
+            else:                  # the shards tile every base array exactly once
+                assert rg[0][key][0] == 0 and rg[k - 1][key][1] == rg[k][key][0]
+
+
+@pytest.mark.parametrize("mode", ["base", "bucket"])
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_two_rank_sharded_proof_gloo(curve, mode):
+    _run_world(2, curve, mode)
+
+
+@pytest.mark.parametrize("curve,mode", [("bls12_381", "bucket"), ("bn254", "base")])
+def test_eight_rank_sharded_proof_gloo(curve, mode):
+    """the world size of the driver's scaling run: b mod 8 residue classes (bucket space) / eight base ranges, the record all-gather
+    over eight ranks and g16_finalize_host folding eight parts (r = 0, s = 0 included) -- on CPU, over gloo"""
+    _run_world(8, curve, mode)
 
 
 def test_shard_ranges_tile():
