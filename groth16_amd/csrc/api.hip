@@ -42,6 +42,30 @@ struct Impl : KeyLoader<C>, Prover<C>, ProofGlue<C>, UnitApi<C> {
 
 static void diag_counts(g16_diag* out) {
     constexpr int NL = B30::NL;
+    out->limbs = NL;
+#ifdef G16_FIPS
+    // product scanning (round 6): NL^2 multiply-adds per sweep and per reduction, 2 per extra accumulator of the column plan -- the same
+    // constexpr plan the assembly blocks are generated from (fp30.hpp fips_plan) -- and NL - 1 per fused subtraction (K p_j - s_j joins
+    // its column with one multiply-add by 1)
+    constexpr auto p1 = B30::template fips_plan<1>();
+    constexpr auto p2 = B30::template fips_plan<2>();
+    constexpr auto p4 = B30::template fips_plan<4>();
+    const double fsub = NL - 1;
+    const double mul = 2.0 * NL * NL + 2.0 * p1.extra, sqr = NL * (NL + 1) / 2.0 + NL * NL + 2.0 * p1.extra;
+    const double two_sweeps = 3.0 * NL * NL + 2.0 * p2.extra;    // two product sweeps + ONE reduction: a lane's Fq2 product; Fp30::mul2_cols
+    const double four_sweeps = 5.0 * NL * NL + 2.0 * p4.extra;   // the lane pair's fused Y
+    out->mads_per_product = mul;
+    // the mixed addition as the bucket pass runs it (AccParked): U2 - x and S2 - y with the subtraction fused, PP, PPP, Q, ZZ*PP, ZZZ*PPP,
+    // R^2 with the X3 subtraction fused, Y as two products under one reduction
+#ifdef G16_NO_FUSED_SUB
+    const double fs = 0.0;
+#else
+    const double fs = fsub;
+#endif
+    out->mads_per_add_g1 = 6 * mul + 2 * sqr + two_sweeps + 3 * fs;
+    // per lane of the pair: six pair products (two sweeps each), two pair squarings (one product each), Y as four sweeps + one reduction
+    out->mads_per_add_g2 = 2 * (6 * two_sweeps + 2 * mul + four_sweeps + 3 * fs);
+#else
     int relax[5] = {0, 0, 0, 0, 0};   // relax[k]: columns relaxed when k sweeps are in and one more (a sweep or the reduction) follows
     for (int c = 0; c + 1 < 2 * NL; ++c)
         for (int k = 1; k <= 4; ++k)
@@ -49,19 +73,10 @@ static void diag_counts(g16_diag* out) {
     const double mul = 2.0 * NL * NL + relax[1], sqr = NL * (NL + 1) / 2.0 + NL * NL + relax[1];
     const double two_sweeps = 3.0 * NL * NL + relax[1] + relax[2];   // two product sweeps + ONE reduction: a lane's Fq2 product; Fp30::mul_sub_cols
     const double four_sweeps = 5.0 * NL * NL + relax[1] + relax[2] + relax[3] + relax[4];   // Fp2p30::pair_mul_sub
-    out->limbs = NL;
     out->mads_per_product = mul;
-    // madd-2008-s as the bucket pass runs it (AccParked, fp30.hpp): U2 S2 PPP Q ZZ*PP ZZZ*PPP + the squarings PP, R^2 + Y3 = R (Q - X3) - Y1 PPP
-    // under one reduction (the register-resident Acc30 of the other kernels spends two products on Y3)
-    const bool fused_g1 = Fp30<typename B30::Params_t>::ACC_PARKED, fused_g2 = Fp2p30<typename B30::Params_t>::ACC_PARKED;
-#ifdef G16_NO_MUL_SUB_FUSED
-    const bool fused = false;
-#else
-    const bool fused = true;
+    out->mads_per_add_g1 = 6 * mul + 2 * sqr + two_sweeps;
+    out->mads_per_add_g2 = 2 * (6 * two_sweeps + 2 * mul + four_sweeps);
 #endif
-    out->mads_per_add_g1 = (fused && fused_g1) ? 6 * mul + 2 * sqr + two_sweeps : 8 * mul + 2 * sqr;
-    // per lane of the pair: pair products (two sweeps each), two pair squarings (one product each), Y3 as four sweeps + one reduction
-    out->mads_per_add_g2 = 2 * ((fused && fused_g2) ? 6 * two_sweeps + 2 * mul + four_sweeps : 8 * two_sweeps + 2 * mul);
 }
 
 // g16_pk_load on a multi-device context: the retry with base ranges after an automatic bucket-space load ran out of memory

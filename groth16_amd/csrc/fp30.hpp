@@ -103,6 +103,29 @@ struct Fp30 {
     }
     // 2p - a, for a <= 2p (used on canonical inputs)
     G16_HD Fp30 neg2() const { return zero().template sub<2>(*this); }
+    // the same on the PACKED form (saturated 32-bit words, as the window tables hold a coordinate), then unpacked: 2p - y is one
+    // subtract-with-borrow per word (12) where the 30-bit limbs need a carry-propagating pass (13 + 36) -- the bucket pass keeps the
+    // gathered y packed until the point is added
+    typedef Fp<P> PackedC;
+    G16_HD static constexpr uint32_t two_p32(int i) { return (P::mod(i) << 1) | (i ? P::mod(i - 1) >> 31 : 0u); }
+    G16_HD static Fp30 unpack_cond_neg(const PackedC& y, bool flip) {
+        uint32_t w[NW];
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned borrow = 0;
+        G16_UNROLL for (int i = 0; i < NW; ++i) {
+            const uint32_t d = __builtin_subc(two_p32(i), y.v[i], borrow, &borrow);
+            w[i] = flip ? d : y.v[i];
+        }
+#else
+        uint32_t borrow = 0;
+        G16_UNROLL for (int i = 0; i < NW; ++i) {
+            const uint64_t t = (uint64_t)two_p32(i) - y.v[i] - borrow;
+            borrow = (uint32_t)(t >> 63);
+            w[i] = flip ? (uint32_t)t : y.v[i];
+        }
+#endif
+        return unpack(w);
+    }
     // canonical a -> a or 2p - a (a signed digit's +-P): a trait so that the bound-propagating stand-in can return the worse of the two
     G16_HD static Fp30 cond_neg2(const Fp30& a, bool flip) { return flip ? a.neg2() : a; }
     // 16p - a, for a < 16p
@@ -534,6 +557,18 @@ struct Fp30 {
         return mul_sub_cols<uint64_t>(a, b, c, d);
 #endif
     }
+    // ---- operand views (round 6).  A lane-pair Fq2 product needs its FIRST operand as both components in both lanes (two DPP
+    // broadcasts per limb) and its SECOND operand's partner component, negated for the even lane (a carry-propagating 16p - b and a
+    // select).  An operand that enters several products of a group formula (PP: three, PPP and Pd and R: two) is prepared ONCE
+    // through these views; for one-lane fields a view is the value itself.
+    typedef Fp30 Lhs;
+    typedef Fp30 Rhs;
+    G16_HD static const Fp30& lhs(const Fp30& a) { return a; }
+    G16_HD static const Fp30& rhs(const Fp30& a) { return a; }
+    G16_HD static Fp30 mul_v(const Fp30& a, const Fp30& b) { return a.mul(b); }
+    G16_HD static Fp30 sqr_v(const Fp30& a) { return a.sqr(); }
+    G16_HD static Fp30 sqr_sub_x3_v(const Fp30& a, const Fp30& u, const Fp30& v) { return a.sqr_sub_x3(u, v); }
+    G16_HD static Fp30 mul_add_fused_v(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) { return mul2_cols<uint64_t>(a, b, c, d); }
     // a*b + c*d under one reduction (the sign-tracking mixed addition's Y: no operand is negated)
     G16_HD static Fp30 mul_add_fused(const Fp30& a, const Fp30& b, const Fp30& c, const Fp30& d) { return mul2_cols<uint64_t>(a, b, c, d); }
     // the fused form unconditionally: AccParked (bucket pass) has the registers for it -- its accumulator is not in them
@@ -619,6 +654,15 @@ struct Fp30 {
         if (p.is_identity()) return false;
         px = from_packed(p.x);
         py = from_packed(p.y);
+        return true;
+    }
+    // the same with y left PACKED (unpack_cond_neg takes it from there when the point is added)
+    template <class A>
+    G16_HD static bool load_point_py(const A* bases, int64_t idx, Fp30& px, PackedC& yw) {
+        const A p = bases[idx];
+        if (p.is_identity()) return false;
+        px = from_packed(p.x);
+        yw = p.y;
         return true;
     }
 
@@ -774,6 +818,14 @@ struct Fp2x30 {
     G16_HD static Fp2x30 mul_sub(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return a.mul(b).template sub<KM>(c.mul(d)); }
     G16_HD static Fp2x30 mul_sub_fused(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return mul_sub(a, b, c, d); }
     G16_HD static Fp2x30 mul_add_fused(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return a.mul(b).add(c.mul(d)); }
+    typedef Fp2x30 Lhs;
+    typedef Fp2x30 Rhs;
+    G16_HD static const Fp2x30& lhs(const Fp2x30& a) { return a; }
+    G16_HD static const Fp2x30& rhs(const Fp2x30& a) { return a; }
+    G16_HD static Fp2x30 mul_v(const Fp2x30& a, const Fp2x30& b) { return a.mul(b); }
+    G16_HD static Fp2x30 sqr_v(const Fp2x30& a) { return a.sqr(); }
+    G16_HD static Fp2x30 sqr_sub_x3_v(const Fp2x30& a, const Fp2x30& u, const Fp2x30& v) { return a.sqr_sub_x3(u, v); }
+    G16_HD static Fp2x30 mul_add_fused_v(const Fp2x30& a, const Fp2x30& b, const Fp2x30& c, const Fp2x30& d) { return mul_add_fused(a, b, c, d); }
     G16_HD Fp2x30 settle() const { return *this; }
     G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     typedef Fp2x30 Raw;
@@ -843,6 +895,14 @@ struct Fp2k30 {
     G16_HD static Fp2k30 mul_sub(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return a.mul(b).template sub<KM>(c.mul(d)); }
     G16_HD static Fp2k30 mul_sub_fused(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return mul_sub(a, b, c, d); }
     G16_HD static Fp2k30 mul_add_fused(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return a.mul(b).add(c.mul(d)); }
+    typedef Fp2k30 Lhs;
+    typedef Fp2k30 Rhs;
+    G16_HD static const Fp2k30& lhs(const Fp2k30& a) { return a; }
+    G16_HD static const Fp2k30& rhs(const Fp2k30& a) { return a; }
+    G16_HD static Fp2k30 mul_v(const Fp2k30& a, const Fp2k30& b) { return a.mul(b); }
+    G16_HD static Fp2k30 sqr_v(const Fp2k30& a) { return a.sqr(); }
+    G16_HD static Fp2k30 sqr_sub_x3_v(const Fp2k30& a, const Fp2k30& u, const Fp2k30& v) { return a.sqr_sub_x3(u, v); }
+    G16_HD static Fp2k30 mul_add_fused_v(const Fp2k30& a, const Fp2k30& b, const Fp2k30& c, const Fp2k30& d) { return mul_add_fused(a, b, c, d); }
     G16_HD Fp2k30 settle() const { return {c0.weak_reduce32(), c1.weak_reduce32()}; }
     G16_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     typedef Fp2x30<P> Raw;
@@ -972,6 +1032,19 @@ struct Fp2p30 {
     G16_HD static Fp2p30 mul_add_fused(const Fp2p30& a, const Fp2p30& b, const Fp2p30& c, const Fp2p30& d) {
         return {pair_mul_add_c(lane_hi(), comp0(a.c), comp1(a.c), b.c, swap(b.c), comp0(c.c), comp1(c.c), d.c, swap(d.c))};
     }
+    // operand views (see Fp30): first operand = both components in both lanes; second operand = this lane's component and what the
+    // product takes from the partner -- lane0: 16p - b1, lane1: b0 -- i.e. the partner's `hi ? 16p - own : own`, one swap away
+    struct Lhs { B a0, a1; };
+    struct Rhs { B m, y2; };
+    G16_HD static Lhs lhs(const Fp2p30& a) { return {comp0(a.c), comp1(a.c)}; }
+    G16_HD static Rhs rhs(const Fp2p30& b) { return {b.c, swap(sel(lane_hi(), b.c.neg16(), b.c))}; }
+    G16_HD static Fp2p30 mul_v(const Lhs& a, const Rhs& b) { return {pair_cols<uint64_t>(a.a0, b.m, a.a1, b.y2)}; }
+    G16_HD static Fp2p30 sqr_v(const Lhs& a) { return {pair_sqr_c(lane_hi(), a.a0, a.a1)}; }
+    G16_HD static Fp2p30 sqr_sub_x3_v(const Lhs& a, const Fp2p30& u, const Fp2p30& v) { return {pair_sqr_sub_x3(lane_hi(), a.a0, a.a1, u.c, v.c)}; }
+    // a b + c d:  lane0: a0 b0 + a1 (16p - b1) + c0 d0 + c1 (16p - d1)      lane1: a0 b1 + a1 b0 + c0 d1 + c1 d0
+    G16_HD static Fp2p30 mul_add_fused_v(const Lhs& a, const Rhs& b, const Lhs& c, const Rhs& d) {
+        return {B::template mul4_cols<uint64_t>(a.a0, b.m, a.a1, b.y2, c.a0, d.m, c.a1, d.y2)};
+    }
     // Measured in round 2 (profiles/r02_ab_mul_sub.txt, 2^22, same box) inside the register-resident accumulator: the fused form was
     // 4.7 % FASTER for G1 (Fp30::mul_sub) but 5 % SLOWER here (27.9 -> 29.3 ms per G2 pass): eight operand sets + the column array
     // exceeded the 256 VGPRs of a two-waves-per-SIMD kernel.  Acc30 therefore keeps two products (G16_PAIR_MUL_SUB opts in); the bucket
@@ -1064,6 +1137,19 @@ struct Fp2p30 {
         py.c = B::unpack(yw.v);
         return true;
     }
+    typedef Fp<P> PackedC;   // this lane's component of y as the table holds it
+    template <class A>
+    G16_HD static bool load_point_py(const A* bases, int64_t idx, Fp2p30& px, PackedC& yout) {
+        const Fp<P>* w = reinterpret_cast<const Fp<P>*>(bases + idx);   // x.c0 x.c1 y.c0 y.c1
+        const int k = lane_hi() ? 1 : 0;
+        const Fp<P> xw = w[k], yw = w[2 + k];
+        const bool zero_half = xw.is_zero() && yw.is_zero();
+        if (both(zero_half)) return false;
+        px.c = B::unpack(xw.v);
+        yout = yw;
+        return true;
+    }
+    G16_HD static Fp2p30 unpack_cond_neg(const PackedC& y, bool flip) { return {B::unpack_cond_neg(y, flip)}; }
 };
 
 // Partial sums between the MSM kernels: the accumulator's lazy limbs verbatim (no conversion, no product), in the layout of
@@ -1321,13 +1407,18 @@ struct AccParked {
     }
     // madd-2008-s: this += (px, +-py), affine canonical px, py, not the identity; `minus`: subtract the point (the signed digit's sign)
     G16_HD void add_affine(const F& px, const F& py) { add_affine_signed(px, py, false); }
-    G16_HD void add_affine_signed(const F& px, const F& py_in, bool minus) {
+    G16_HD bool flip_for(bool minus) const {
 #ifdef G16_NO_SIGN_TRACK
-        const bool flip = minus;
+        return minus;
 #else
-        const bool flip = minus != (neg && !inf);   // the point takes the parked sum's sign as well
+        return minus != (neg && !inf);   // the point takes the parked sum's sign as well
 #endif
-        const F py = F::cond_neg2(py_in, flip);
+    }
+    G16_HD void add_affine_signed(const F& px, const F& py_in, bool minus) { add_affine_core(px, F::cond_neg2(py_in, flip_for(minus))); }
+    // y as the window table holds it (packed words): negated there -- one subtract-with-borrow per word -- and unpacked once
+    template <class YP>
+    G16_HD void add_affine_packed(const F& px, const YP& yw, bool minus) { add_affine_core(px, F::unpack_cond_neg(yw, flip_for(minus))); }
+    G16_HD void add_affine_core(const F& px, const F& py) {
         if (inf) {
             s.st(CX, px); s.st(CY, py); s.st(CZZ, F::one()); s.st(CZZZ, F::one());
             inf = false;
@@ -1343,24 +1434,37 @@ struct AccParked {
                 return;
             }
         }
+#if defined(G16_NO_OPERAND_VIEWS) || defined(G16_NO_SIGN_TRACK)
         const F PP = Pd.sqr();
         s.st(CZZ, s.ld(CZZ).mul(PP));
         const F PPP = Pd.mul(PP);
         s.st(CZZZ, s.ld(CZZZ).mul(PPP));
         const F Q = s.ld(CX).mul(PP);
-        // X3 = R^2 - (PPP + 2 Q): the subtrahend is formed with one normalisation and subtracted once (K = KM + K2M: the same bound
-        // as two subtractions) -- two normalisation sweeps and a doubling less than R^2 - PPP - 2Q taken term by term
-#ifdef G16_NO_FUSED_X3
-        const F X3 = R.sqr().template sub<F::KM>(PPP).template sub<F::K2M>(Q.dbl()).settle();
-#else
         static_assert(F::KM + F::K2M == 6, "sqr_sub_x3 subtracts from 6 p");
-        const F X3 = R.sqr_sub_x3(PPP, Q).settle();   // R^2 + 6 p - (PPP + 2 Q), the subtraction inside the squaring's high columns
-#endif
+        const F X3 = R.sqr_sub_x3(PPP, Q).settle();
         s.st(CX, X3);
 #ifdef G16_NO_SIGN_TRACK
         s.st(CY, F::mul_sub_fused(R, Q.template sub<F::KX>(X3), s.ld(CY), PPP).settle());
 #else
         s.st(CY, F::mul_add_fused(R, X3.template sub<F::KM>(Q), s.ld(CY), PPP).settle());   // = -Y3: the parked sum changes sign
+        neg = !neg;
+#endif
+#else
+        // every operand that enters more than one product is prepared once (F::lhs / F::rhs: the lane pair's broadcasts / negation)
+        const typename F::Lhs PdL = F::lhs(Pd);
+        const F PP = F::sqr_v(PdL);
+        const typename F::Rhs PPr = F::rhs(PP);
+        s.st(CZZ, F::mul_v(F::lhs(s.ld(CZZ)), PPr));
+        const F PPP = F::mul_v(PdL, PPr);
+        const typename F::Rhs PPPr = F::rhs(PPP);
+        s.st(CZZZ, F::mul_v(F::lhs(s.ld(CZZZ)), PPPr));
+        const F Q = F::mul_v(F::lhs(s.ld(CX)), PPr);
+        static_assert(F::KM + F::K2M == 6, "sqr_sub_x3 subtracts from 6 p");
+        const typename F::Lhs RL = F::lhs(R);
+        const F X3 = F::sqr_sub_x3_v(RL, PPP, Q).settle();   // R^2 + 6 p - (PPP + 2 Q), the subtraction inside the squaring's high columns
+        s.st(CX, X3);
+        // R (X3 - Q) + y PPP = -Y3: a SUM of products, so the parked sum changes sign (see `neg`)
+        s.st(CY, F::mul_add_fused_v(RL, F::rhs(X3.template sub<F::KM>(Q)), F::lhs(s.ld(CY)), PPPr).settle());
         neg = !neg;
 #endif
     }

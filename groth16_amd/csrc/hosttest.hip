@@ -96,6 +96,22 @@ struct BoundF {
         if (ctx().pair) return product(A, bb.b > 16.0 ? bb.b : 16.0, a.b * bb.b + a.b * (bb.b > 16.0 ? bb.b : 16.0) + c.b * d.b + 2.0 * c.b);
         return product(A, bb.b > d.b ? bb.b : d.b, a.b * bb.b + c.b * d.b);
     }
+    // operand views (fp30.hpp): the lane pair's prepared second operand is its own component and the partner's, negated from 16p
+    typedef BoundF Lhs;
+    typedef BoundF Rhs;
+    static BoundF lhs(const BoundF& a) { return a; }
+    static BoundF rhs(const BoundF& a) { check(!ctx().pair || a.b <= 16.0 - 1e-3, "rhs: operand not below 16p"); return a; }
+    static BoundF mul_v(const BoundF& a, const BoundF& b) { return a.mul(b); }
+    static BoundF sqr_v(const BoundF& a) { return a.sqr(); }
+    static BoundF sqr_sub_x3_v(const BoundF& a, const BoundF& u, const BoundF& v) { return a.sqr_sub_x3(u, v); }
+    static BoundF mul_add_fused_v(const BoundF& a, const BoundF& bb, const BoundF& c, const BoundF& d) {
+        const double A = a.b > c.b ? a.b : c.b;
+        if (ctx().pair) {   // a0 b0 + a1 (16p - b1) + c0 d0 + c1 (16p - d1)
+            const double Bb = bb.b > 16.0 ? bb.b : 16.0, Db = d.b > 16.0 ? d.b : 16.0;
+            return product(A, Bb > Db ? Bb : Db, a.b * bb.b + a.b * Bb + c.b * d.b + c.b * Db);
+        }
+        return product(A, bb.b > d.b ? bb.b : d.b, a.b * bb.b + c.b * d.b);
+    }
     BoundF settle() const { return *this; }
     bool maybe_zero() const { check(b < 16.0, "zero test on a value not below 16p"); return false; }
     bool is_zero_exact() const { check(b < 16.0, "zero test on a value not below 16p"); return false; }
@@ -662,8 +678,14 @@ struct SelfTest {
             park.set_identity();
             G1X ref = G1X::identity();
             for (size_t i = 0; i < seq.size(); ++i) {
+                {   // the packed conditional negation against the limb form's
+                    const Fq yw = F30::std_to_r30(seq[i].y);
+                    if (!F30::unpack_cond_neg(yw, true).same_limbs(F30::unpack(yw.v).neg2()) || !F30::unpack_cond_neg(yw, false).same_limbs(F30::unpack(yw.v)))
+                        return 5090;
+                }
                 acc.add_affine(to30(seq[i].x), to30(seq[i].y));
-                park.add_affine(to30(seq[i].x), to30(seq[i].y));
+                if (i & 1) park.add_affine_packed(to30(seq[i].x), F30::std_to_r30(seq[i].y), false);   // both entries of the parked form
+                else park.add_affine(to30(seq[i].x), to30(seq[i].y));
                 ref.add_affine(seq[i]);
                 const G1A got = acc.to_std().to_affine(), want = ref.to_affine();
                 if (!(got == want)) return 100 + round * 100 + (int)i;

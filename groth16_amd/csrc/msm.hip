@@ -557,7 +557,11 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
     // ~20k-instruction addition of entry e, so the HBM latencies hide under arithmetic.  (Touching the cache lines of
     // entry e+2 with direct-to-LDS loads was tried for the window tables' wider gather: 25 % slower.)
     uint32_t v_next = 0;
-    F30 px_next = F30::zero(), py_next = F30::zero();
+    // a parked accumulator takes y PACKED (12 words as gathered): the signed digit's negation costs one subtract-with-borrow per word
+    // there, and the unpacking happens once, when the point is added (AccParked::add_affine_packed)
+    typedef typename std::conditional<F30::ACC_PARKED, typename F30::PackedC, F30>::type YNext;
+    F30 px_next = F30::zero();
+    YNext py_next = YNext::zero();
     bool ok_next = false;
     auto decode = [&](uint32_t v, int64_t* at) -> bool {
         // per-window plan: entry = point | sign<<31 ; merged plan: point | window<<26 | sign<<31, base = table[window][point]
@@ -571,7 +575,10 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         v_next = DIRECT ? 0u : v;
         int64_t at = (int64_t)v;
         ok_next = DIRECT ? true : decode(v, &at);
-        if (ok_next) ok_next = F30::load_point(bases, at, px_next, py_next);
+        if (ok_next) {
+            if constexpr (F30::ACC_PARKED) ok_next = F30::load_point_py(bases, at, px_next, py_next);
+            else ok_next = F30::load_point(bases, at, px_next, py_next);
+        }
     };
     fetch(DIRECT ? start : sorted[start]);
     uint32_t v_fetch = DIRECT ? start + 1 : (start + 1 < end ? sorted[start + 1] : 0u);   // entry e+1's word, loaded one iteration early
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         }
         const uint32_t v = v_next;
         const F30 px = px_next;
-        F30 py = py_next;
+        YNext py = py_next;
         const bool ok = ok_next;
         auto advance = [&]() {
             if (e + 1 < end) fetch(v_fetch);
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(ACC_THREADS, F30::ACC_MIN_WAVES) void bucket_accumu
         if constexpr (F30::ACC_PREFETCH) advance();
         if (ok) {
             if constexpr (F30::ACC_PARKED) {
-                acc.add_affine_signed(px, py, (v >> 31) != 0);   // the digit's sign and the parked sum's sign are one flip (AccParked)
+                acc.add_affine_packed(px, py, (v >> 31) != 0);   // the digit's sign and the parked sum's sign are one flip (AccParked)
             } else {
                 if (v >> 31) py = py.neg2();
                 acc.add_affine(px, py);

@@ -13,3 +13,11 @@ extern "C" __global__ void k_2mul(F* a, const F* b) { const int i = threadIdx.x;
 typedef Fp2p30<P> F2;
 extern "C" __global__ void k_pair_mul(F2* a, const F2* b) { const int i = threadIdx.x; const F2 x = a[i], y = b[i]; a[i] = x.mul(y); }
 extern "C" __global__ void k_pair_mulsub(F2* a, const F2* b) { const int i = threadIdx.x; const F2 x = a[i], y = b[i], z = a[i + 64], w = b[i + 64]; a[i] = F2::mul_sub_fused(x, y, z, w); }
+extern "C" __global__ void k_negpk(F* a, const Fp<P>* b, const int* f) {
+    const int i = threadIdx.x;
+    a[i] = F::unpack_cond_neg(b[i], f[i] != 0);
+}
+extern "C" __global__ void k_negold(F* a, const Fp<P>* b, const int* f) {
+    const int i = threadIdx.x;
+    a[i] = F::cond_neg2(F::from_packed(b[i]), f[i] != 0);
+}
