@@ -168,8 +168,8 @@ int main() {
             }
         }
         const double prods = 65536.0 * w * iters;
-        printf("MFMA-GLUE waves/SIMD=%d  per product: sweep (169 v_mad_u64_u32) %.3f ns-chip | split + recombine on the vector pipe %.3f | 28 MFMA / 64 products %.3f | 128 ds_bpermute / 64 products %.3f   "
-               "=> vector-pipe time of the MFMA variant / sweep = %.2f\n", w, ms[0] * 1e6 / prods, ms[1] * 1e6 / prods, ms[2] * 1e6 / prods, ms[3] * 1e6 / prods, ms[1] / ms[0]);
+        printf("MFMA-GLUE waves/SIMD=%d  per product: sweep (169 v_mad_u64_u32) %.2f ps of chip time | split + recombine on the vector pipe %.2f | 28 MFMA / 64 products %.2f | 128 ds_bpermute / 64 products %.2f   "
+               "=> vector-pipe time of the MFMA variant / sweep = %.2f\n", w, ms[0] * 1e9 / prods, ms[1] * 1e9 / prods, ms[2] * 1e9 / prods, ms[3] * 1e9 / prods, ms[1] / ms[0]);
     }
     return 0;
 }
