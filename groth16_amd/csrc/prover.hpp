@@ -208,7 +208,10 @@ struct Prover {
             RoctxRange rr("Compute B in G2");                                                                 // prover.rs:111
             if (concurrent) {
                 G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_z, 0));
-                G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_wm, 0));   // never underneath the witness map (it would starve)
+                // never underneath the witness map (it would starve).  (Sharded proof, round 6: the G2 pass started behind the witness sort
+                // only, the distributed map's remaining links beside it, with four-wave and with one-wave transform workgroups:
+                // 9.93 - 10.2 ms per rank in every arrangement, profiles/r06_ab_g2_before_dist_map.txt -- the share is work, not waiting.)
+                G16_HIP_TRY(hipStreamWaitEvent(sr, ctx->ev_wm, 0));
                 G16_TRY(run_pass(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2, sr));
             } else {
                 G16_TRY(run_pass(4, pk->b_g2, 0, pk->b_g2_count, sort_z, &buf_b2));                           // prover.rs:113
