@@ -300,7 +300,8 @@ def main():
     for sname, name, n_ins, n_mad in stats:
         out.append("//   %-14s %-5s %4d [%4d]" % (sname, name, n_ins, n_mad))
     out.append("}  // namespace g16")
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fips_asm_gen.hpp")
+    import sys
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "fips_asm_gen.hpp")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
     print("wrote", path)
