@@ -4,7 +4,12 @@
 set -u
 TAG=$1; O=gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 NOX="--no-cpu-baseline --no-pipelined --no-projection"
-timeout 120 tools/bin/probe_mfma > $O/probe_mfma.txt 2>&1; cat $O/probe_mfma.txt
+if [ "${2:-}" = "full" ]; then   # the GPU tier and smoke() first (the round's LAST tree)
+  timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -9 $O/pytest_gpu.log
+  timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+else
+  timeout 120 tools/bin/probe_mfma > $O/probe_mfma.txt 2>&1; cat $O/probe_mfma.txt
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p $O/pmc_$c
   timeout 200 rocprofv3 --pmc $c -d $O/pmc_$c/calib -o pmc --output-format csv -- tools/bin/calib > $O/calib_$c.jsonl 2> $O/calib_$c.err
@@ -29,3 +34,5 @@ print({k: d[k] for k in ("value", "ms_per_step", "value_survey_8d")}, "traffic",
 print("G1 launch", r["avg_launch_ms"], "x", r["launches_per_step"], "frac", r["frac"], "valu", r["valu_bound"]["frac"], "peak", r["valu_bound"]["measured_peak_Tmad_s"])
 print([(q["shard_mode"], q["n_gpus"], q["rank_share_ms"], q["projected_speedup"]) for q in d["projected_scaling"]["points"]])
 PY
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 $NOX > $O/bench_stats.json 2> $O/bench_stats.err; echo "stats rc=$?"
+find $O/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_k22_kernel_stats.csv; rm -rf $O/prof_stats; head -4 $O/bench_k22_kernel_stats.csv | cut -c1-200
