@@ -733,20 +733,20 @@ def main():
     # current stream, max over ranks): the terms a measured N > 1 line can be compared with the one-GPU projection by -- the projection
     # holds everything but these
     collective_ms = None
-    if dist is not None and world > 1 and backend == "nccl":
+    if dist is not None and world > 1:
         collective_ms = {}
 
         def time_coll(fn, reps=5):
+            # host clock around `reps` calls with the device drained on both sides (works for RCCL and for the test tier's gloo, whose
+            # tensors live on the host); the per-call launch overhead (~20 us) is inside
             fn()
             torch.cuda.synchronize()
             dist.barrier()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            t_a = time.perf_counter()
             for _ in range(reps):
                 fn()
-            e1.record()
             torch.cuda.synchronize()
-            t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=device)
+            t = torch.tensor([1e3 * (time.perf_counter() - t_a) / reps], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return round(float(t.item()), 4)
 
@@ -761,10 +761,11 @@ def main():
             collective_ms["all_to_all_one_array"] = one
             collective_ms["all_to_all_per_proof_x7"] = round(7 * one, 4)
             if p.mode == "bucket":
-                hf = torch.empty((M * world, 4), dtype=torch.int64, device=device)
-                collective_ms["h_all_gather"] = time_coll(lambda: dist.all_gather_into_tensor(hf, a2a_src))
+                hparts = [torch.empty_like(a2a_src) for _ in range(world)]
+                collective_ms["h_all_gather"] = time_coll(lambda: dist.all_gather(hparts, a2a_src))
+                del hparts
             del a2a_src, a2a_dst
-        collective_ms["note"] = ("each collective timed alone (5 calls back to back, HIP events, max over ranks); inside a proof they are "
+        collective_ms["note"] = ("each collective timed alone (5 calls back to back, host clock with the device drained, max over ranks); inside a proof they are "
                                  "enqueued on the witness-map stream beside the witness sort")
 
     # PCIe-inclusive rates (SURVEY.md 8(d) defines the metric with the witness on the host at entry; `value` above is the

@@ -572,6 +572,9 @@ def test_bench_two_ranks_one_gpu(launcher):
     assert d2["config"]["shard_mode"] == want_mode and d2["config"]["pk"]["table_fallback"] == 0
     assert d2["config"]["pk"]["bucket_shard_world"] == (2 if want_mode == "bucket" else 1)
     assert d2["configs4"]["shard_mode"] == want_mode
+    # round 6: the collectives of a sharded proof, each timed alone (the terms a measured N > 1 line is compared with the projection by)
+    cm = d2["collective_ms"]
+    assert cm["record_all_gather"] > 0 and (d2["config"].get("parallelism", "").find("distributed witness map") < 0 or cm["all_to_all_one_array"] > 0), cm
     # the single-GPU line carries the projected per-rank shares at 2 / 4 / 8 ranks under both cuts (measured on this GPU), and the
     # key is whole again afterwards
     ps = d1["projected_scaling"]
